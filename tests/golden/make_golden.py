@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures from the REAL reference classes (CPU, fp32).
+
+Run in the build container only (needs /root/reference):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+Import recipe: stub cv2 (util.py:3 imports it, the hot path never
+calls it), put /root/reference/src on sys.path, import util BEFORE generator
+(import cycle util.py:13 <-> generator.py:8).  trainer.py is not importable
+(evan/skvideo/colorlog/tensorboardX are absent), so the iteration of
+trainer.py:279-363 is driven here directly on the reference's module, loss and
+torch.optim.Adam objects (train.py:171-176).
+
+Fixtures are DATA only: seeds, initial state_dicts, inputs, expected outputs,
+gradients and checksums.  No reference source is stored.
+
+Random draws are not stored (they are megabytes); a fixture records the seed
+and the oracle re-draws from the same CPU generator in the same order.  That
+the order is right is exactly what tests/test_oracle_golden.py proves.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src"
+
+
+def import_reference():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, REF)
+    import util  # noqa: F401  (must come first)
+    import generator, discriminator, loss  # noqa: E401
+    return util, generator, discriminator, loss
+
+
+def sub(t: torch.Tensor, step: int = 37) -> np.ndarray:
+    """Strided sample of a big activation (keeps fixtures small)."""
+    return t.detach().contiguous().view(-1)[::step].numpy().copy()
+
+
+def summ(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def put_state(out, prefix, sd):
+    for k, v in sd.items():
+        out[f"{prefix}/{k}"] = v.detach().clone().numpy()
+
+
+def build_models(ref, cfg, seed):
+    util, generator, discriminator, loss = ref
+    torch.manual_seed(seed)
+    ggen = generator.GeometricVideoGenerator(cfg["dzc"], cfg["dzm"], cfg["Cg"], cfg["geo"], cfg["ngf_g"], 16)
+    cgen = generator.ColorVideoGenerator(ggen.channel, cfg["dzcol"], cfg["geo"], cfg["ngf_c"], 16)
+    idis = discriminator.ImageDiscriminator(ggen.channel, cgen.channel, cfg["noise_i"][0], cfg["noise_i"][1], cfg["ndf_i"])
+    vdis = discriminator.VideoDiscriminator(ggen.channel, cgen.channel, cfg["noise_v"][0], cfg["noise_v"][1], cfg["ndf_v"])
+    gdis = discriminator.GradientDiscriminator(ggen.channel, cgen.channel, cfg["noise_g"][0], cfg["noise_g"][1], cfg["ndf_g"])
+    models = dict(ggen=ggen, cgen=cgen, idis=idis, vdis=vdis, gdis=gdis)
+    for m in models.values():
+        m.apply(util.init_weights)  # train.py:164-165
+    return models
+
+
+def cfg_meta(out, cfg):
+    for k, v in cfg.items():
+        if isinstance(v, tuple):
+            out[f"cfg/{k}"] = np.array([float(v[0]), float(v[1])])
+        elif isinstance(v, str):
+            out[f"cfg/{k}"] = np.array(v)
+        else:
+            out[f"cfg/{k}"] = np.array(v)
+
+
+# --------------------------------------------------------------------------- #
+# module-level fixture: forward outputs + all parameter gradients
+# --------------------------------------------------------------------------- #
+def module_fixture(ref, cfg, name, B=2, seed=1234):
+    out = {}
+    cfg_meta(out, cfg)
+    out["meta/B"] = np.array(B)
+    out["meta/seed_init"] = np.array(seed)
+    models = build_models(ref, cfg, seed)
+    for n, m in models.items():
+        put_state(out, f"init/{n}", m.state_dict())
+    ggen, cgen, idis, vdis, gdis = (models[k] for k in ("ggen", "cgen", "idis", "vdis", "gdis"))
+
+    # ---- generators, train mode: seed -> sample -> colourise ----
+    s_fwd = seed + 1
+    out["meta/seed_gen_train"] = np.array(s_fwd)
+    torch.manual_seed(s_fwd)
+    ggen.train(); cgen.train()
+    xg = ggen.sample_videos(B)
+    xc = cgen.forward_videos(xg)
+    out["gen_train/xg_stride"] = np.array(xg.stride())
+    out["gen_train/xc_stride"] = np.array(xc.stride())
+    out["gen_train/xg_sub"] = sub(xg); out["gen_train/xg_sum"] = summ(xg)
+    out["gen_train/xc_sub"] = sub(xc); out["gen_train/xc_sum"] = summ(xc)
+    # fixed cotangents (deterministic, seed-free)
+    n_g, n_c = xg.numel(), xc.numel()
+    cot_g = torch.cos(torch.arange(n_g, dtype=torch.float32) * 0.37).view(xg.shape)
+    cot_c = torch.sin(torch.arange(n_c, dtype=torch.float32) * 0.11).view(xc.shape)
+    ((xg * cot_g).sum() + (xc * cot_c).sum()).backward()
+    for n in ("ggen", "cgen"):
+        for k, p in models[n].named_parameters():
+            out[f"gen_train/grad/{n}/{k}"] = p.grad.clone().numpy()
+        put_state(out, f"gen_train/after/{n}", {k: v for k, v in models[n].state_dict().items() if "running" in k or "num_batches" in k})
+        models[n].zero_grad()
+
+    # ---- generators, eval mode (running stats, no dropout) ----
+    s_eval = seed + 2
+    out["meta/seed_gen_eval"] = np.array(s_eval)
+    torch.manual_seed(s_eval)
+    ggen.eval(); cgen.eval()
+    with torch.no_grad():
+        xg_e = ggen.sample_videos(B)
+        xc_e = cgen.forward_videos(xg_e)
+    out["gen_eval/xg_sub"] = sub(xg_e); out["gen_eval/xg_sum"] = summ(xg_e)
+    out["gen_eval/xc_sub"] = sub(xc_e); out["gen_eval/xc_sum"] = summ(xc_e)
+    ggen.train(); cgen.train()
+
+    # ---- discriminators on fixed inputs (non-contiguous, like the trainer feeds) ----
+    s_in = seed + 3
+    g = torch.Generator().manual_seed(s_in)
+    out["meta/seed_dis_inputs"] = np.array(s_in)
+    # memory order (B,T,C,H,W) viewed as (B,C,T,H,W): the generators' output layout
+    xg_in = (torch.rand(B, 16, cfg["Cg"], 64, 64, generator=g) * 2 - 1).permute(0, 2, 1, 3, 4).requires_grad_(True)
+    xc_in = (torch.rand(B, 16, 3, 64, 64, generator=g) * 2 - 1).permute(0, 2, 1, 3, 4).requires_grad_(True)
+    s_d = seed + 4
+    out["meta/seed_dis_fwd"] = np.array(s_d)
+    torch.manual_seed(s_d)
+    t = 5
+    out["meta/t_rand"] = np.array(t)
+    for m in (idis, vdis, gdis):
+        m.train()
+    yi = idis(xg_in[:, :, t], xc_in[:, :, t])
+    yv = vdis(xg_in, xc_in)
+    yg = gdis(xg_in, xc_in)
+    out["dis/yi"] = yi.detach().numpy().copy()
+    out["dis/yv"] = yv.detach().numpy().copy()
+    out["dis/yg"] = yg.detach().numpy().copy()
+    tot = (yi * torch.linspace(-1, 1, yi.numel()).view(yi.shape)).sum() \
+        + (yv * torch.linspace(1, -1, yv.numel()).view(yv.shape)).sum() \
+        + (yg * torch.linspace(-0.5, 1.5, yg.numel()).view(yg.shape)).sum()
+    gin = torch.autograd.grad(tot, [xg_in, xc_in], retain_graph=True)
+    out["dis/grad_xg_sub"] = sub(gin[0], 11); out["dis/grad_xg_sum"] = summ(gin[0])
+    out["dis/grad_xc_sub"] = sub(gin[1], 11); out["dis/grad_xc_sum"] = summ(gin[1])
+    tot.backward()
+    for n in ("idis", "vdis", "gdis"):
+        for k, p in models[n].named_parameters():
+            out[f"dis/grad/{n}/{k}"] = p.grad.clone().numpy()
+        put_state(out, f"dis/after/{n}", {k: v for k, v in models[n].state_dict().items() if "running" in k or "num_batches" in k})
+
+    # ---- losses on the three real logit shapes ----
+    _, _, _, loss = ref
+    gl = torch.Generator().manual_seed(seed + 5)
+    ys = [torch.randn(s, generator=gl) * 2 for s in ((B, 4, 4), (B, 4, 4, 4), (B, 3, 4, 4))]
+    for lname, L in (("adv", loss.AdversarialLoss()), ("hinge", loss.HingeLoss())):
+        for i, y in enumerate(ys):
+            yr = y.clone().requires_grad_(True)
+            yf = (y.flip(0) * 0.7 + 0.1).clone().requires_grad_(True)
+            v = L.compute_dis_loss(yr, yf)
+            gr, gf = torch.autograd.grad(v, [yr, yf])
+            out[f"loss/{lname}/dis{i}/yr"] = yr.detach().numpy().copy()
+            out[f"loss/{lname}/dis{i}/yf"] = yf.detach().numpy().copy()
+            out[f"loss/{lname}/dis{i}/value"] = np.array(v.item())
+            out[f"loss/{lname}/dis{i}/gr"] = gr.numpy().copy()
+            out[f"loss/{lname}/dis{i}/gf"] = gf.numpy().copy()
+        yq = [y.clone().requires_grad_(True) for y in ys]
+        v = L.compute_gen_loss(*yq)
+        gq = torch.autograd.grad(v, yq, allow_unused=True)
+        out[f"loss/{lname}/gen/value"] = np.array(v.item())
+        for i, gg in enumerate(gq):
+            out[f"loss/{lname}/gen/g{i}"] = (gg if gg is not None else torch.zeros_like(ys[i])).numpy().copy()
+    np.savez(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+# --------------------------------------------------------------------------- #
+# step-level fixture: trainer.py:279-363 driven on the reference objects
+# --------------------------------------------------------------------------- #
+def step_fixture(ref, cfg, name, loss_name, num_gen_update, start_in_eval, B=2, iters=3, seed=77):
+    util, generator, discriminator, loss = ref
+    out = {}
+    cfg_meta(out, cfg)
+    out["meta/B"] = np.array(B); out["meta/iters"] = np.array(iters)
+    out["meta/loss"] = np.array(loss_name); out["meta/num_gen_update"] = np.array(num_gen_update)
+    out["meta/num_dis_update"] = np.array(1)
+    out["meta/start_in_eval"] = np.array(int(start_in_eval))
+    out["meta/seed_init"] = np.array(seed)
+    models = build_models(ref, cfg, seed)
+    for n, m in models.items():
+        put_state(out, f"init/{n}", m.state_dict())
+    ggen, cgen, idis, vdis, gdis = (models[k] for k in ("ggen", "cgen", "idis", "vdis", "gdis"))
+    L = loss.AdversarialLoss() if loss_name == "adversarial-loss" else loss.HingeLoss()
+    lrs = dict(ggen=2e-4, cgen=2e-4, idis=5e-4, vdis=5e-4, gdis=2e-4)
+    opt = {n: torch.optim.Adam(m.parameters(), lr=lrs[n], betas=(0.5, 0.999), weight_decay=1e-5) for n, m in models.items()}
+    for n, v in lrs.items():
+        out[f"meta/lr/{n}"] = np.array(v)
+    gdata = torch.Generator().manual_seed(seed + 1)
+    lo, hi = (-0.5, 0.5) if cfg["Cg"] == 2 else (-1.0, 1.0)
+    xc_real = torch.rand(B, 3, 16, 64, 64, generator=gdata) * 2 - 1
+    xg_real = torch.rand(B, cfg["Cg"], 16, 64, 64, generator=gdata) * (hi - lo) + lo
+    out["meta/seed_data"] = np.array(seed + 1)
+    t_rands = [3, 11, 0, 15, 7][:iters]
+    out["meta/t_rands"] = np.array(t_rands)
+    out["meta/seed_run"] = np.array(seed + 2)
+    torch.manual_seed(seed + 2)
+    if start_in_eval:  # trainer.py:266-267 leaves the generators in eval()
+        ggen.eval(); cgen.eval()
+    losses = []
+    for it in range(1, iters + 1):
+        t = t_rands[it - 1]
+        idis.train(); vdis.train(); gdis.train()
+        idis.zero_grad(); vdis.zero_grad(); gdis.zero_grad()
+        y_real_i = idis(xg_real[:, :, t], xc_real[:, :, t])
+        y_real_v = vdis(xg_real, xc_real)
+        y_real_g = gdis(xg_real, xc_real)
+        xg_fake = ggen.sample_videos(B)
+        xc_fake = cgen.forward_videos(xg_fake)
+        y_fake_i = idis(xg_fake[:, :, t], xc_fake[:, :, t])
+        y_fake_v = vdis(xg_fake, xc_fake)
+        y_fake_g = gdis(xg_fake, xc_fake)
+        loss_idis = L.compute_dis_loss(y_real_i, y_fake_i)
+        loss_vdis = L.compute_dis_loss(y_real_v, y_fake_v)
+        loss_gdis = L.compute_dis_loss(y_real_g, y_fake_g)
+        loss_dis = loss_idis + loss_vdis + loss_gdis
+        if it % num_gen_update == 0:
+            loss_dis.backward()
+            opt["idis"].step(); opt["vdis"].step(); opt["gdis"].step()
+        ggen.train(); cgen.train()
+        ggen.zero_grad(); cgen.zero_grad()
+        xg_fake = ggen.sample_videos(B)
+        xc_fake = cgen.forward_videos(xg_fake)
+        y_fake_i = idis(xg_fake[:, :, t], xc_fake[:, :, t])
+        y_fake_v = vdis(xg_fake, xc_fake)
+        y_fake_g = gdis(xg_fake, xc_fake)
+        loss_gen = L.compute_gen_loss(y_fake_i, y_fake_v, y_fake_g)
+        loss_gen.backward()
+        opt["ggen"].step(); opt["cgen"].step(); opt["ggen"].step()
+        losses.append([loss_idis.item(), loss_vdis.item(), loss_gdis.item(), loss_gen.item()])
+        for n, m in models.items():
+            for k, v in m.state_dict().items():
+                v = v.detach().float().reshape(-1)
+                out[f"after{it}/{n}/{k}"] = np.concatenate([
+                    np.array([v.double().abs().sum().item(), v.double().sum().item()]),
+                    v[:8].double().numpy()])
+    out["losses"] = np.array(losses)
+    np.savez(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB", losses)
+
+
+# --------------------------------------------------------------------------- #
+# full-width scalars (real channel counts, values only)
+# --------------------------------------------------------------------------- #
+def fullwidth_fixture(ref, cfg, name, B=2, seed=99):
+    util, generator, discriminator, loss = ref
+    out = {}
+    cfg_meta(out, cfg)
+    out["meta/B"] = np.array(B); out["meta/seed_init"] = np.array(seed)
+    # states are re-derivable: same constructor order under the same seed
+    models = build_models(ref, cfg, seed)
+    for n, m in models.items():
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                out[f"init_sum/{n}/{k}"] = summ(v)
+    ggen, cgen, idis, vdis, gdis = (models[k] for k in ("ggen", "cgen", "idis", "vdis", "gdis"))
+    torch.manual_seed(seed + 1)
+    out["meta/seed_run"] = np.array(seed + 1)
+    xg = ggen.sample_videos(B); xc = cgen.forward_videos(xg)
+    t = 9
+    out["meta/t_rand"] = np.array(t)
+    yi = idis(xg[:, :, t], xc[:, :, t]); yv = vdis(xg, xc); yg = gdis(xg, xc)
+    L = loss.AdversarialLoss()
+    v = L.compute_gen_loss(yi, yv, yg)
+    v.backward()
+    out["loss_gen"] = np.array(v.item())
+    out["xg_sum"] = summ(xg); out["xc_sum"] = summ(xc)
+    out["yi"] = yi.detach().numpy().copy(); out["yv"] = yv.detach().numpy().copy(); out["yg"] = yg.detach().numpy().copy()
+    for n, m in models.items():
+        for k, p in m.named_parameters():
+            out[f"gradnorm/{n}/{k}"] = np.array(p.grad.double().norm().item())
+    np.savez(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB")
+    return models
+
+
+if __name__ == "__main__":
+    ref = import_reference()
+    torch.set_num_threads(8)
+    small_depth = dict(geo="depth", Cg=1, dzc=5, dzm=3, dzcol=3, ngf_g=6, ngf_c=6, ndf_i=6, ndf_v=6, ndf_g=4,
+                       noise_i=(True, 0.1), noise_v=(True, 0.1), noise_g=(False, 0.2))
+    small_flow = dict(geo="optical-flow", Cg=2, dzc=4, dzm=2, dzcol=2, ngf_g=4, ngf_c=4, ndf_i=4, ndf_v=4, ndf_g=4,
+                      noise_i=(True, 0.2), noise_v=(True, 0.2), noise_g=(True, 0.2))
+    module_fixture(ref, small_depth, "modules_depth_w6.npz")
+    module_fixture(ref, small_flow, "modules_flow_w4.npz")
+    step_fixture(ref, small_depth, "step_depth_adv_g1.npz", "adversarial-loss", 1, False)
+    step_fixture(ref, small_depth, "step_depth_adv_g1_evalstart.npz", "adversarial-loss", 1, True)
+    step_fixture(ref, small_flow, "step_flow_hinge_g2.npz", "hinge-loss", 2, False)
+    full = dict(geo="depth", Cg=1, dzc=40, dzm=10, dzcol=10, ngf_g=64, ngf_c=64, ndf_i=64, ndf_v=64, ndf_g=32,
+                noise_i=(True, 0.1), noise_v=(True, 0.1), noise_g=(False, 0.2))
+    fullwidth_fixture(ref, full, "fullwidth_isogd_depth.npz")
