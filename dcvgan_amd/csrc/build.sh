@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libdcvgan_hip.so for gfx950 (in-tree; the .so travels to the GPU box).
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../libdcvgan_hip.so"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+mkdir -p "$HERE/obj"
+pids=()
+for f in conv_mfma elementwise; do
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/dcv_common.h" -nt "$HERE/obj/$f.o" ] || [ "$ROOT/include/dcvgan_hip.h" -nt "$HERE/obj/$f.o" ]; then
+    hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/conv_mfma.o" "$HERE/obj/elementwise.o"
+echo "built $OUT"

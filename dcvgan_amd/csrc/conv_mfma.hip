@@ -1,0 +1,869 @@
+// Implicit-GEMM convolutions for gfx950 on v_mfma_f32_32x32x2_f32.
+//
+// Every conv / transposed conv / data-gradient of the DCVGAN step is ONE of two
+// GEMM shapes over NCDHW tensors (never re-laid-out, strides are honoured):
+//
+//  gather GEMM   Y[oc, m] = sum_k  Wp[k, oc] * Xg[k, m]       (fprop, dgrad, convT)
+//      m  = (n, od, oh, ow) output position (one stride-parity class per launch
+//           for the "scatter" forms), k = (reduction channel, tap);
+//      Xg = the gathered input, zero outside the tensor;
+//      Wp = weights re-packed K-major once per call by pack_weights_kernel.
+//      MFMA A operand = weights (rows = oc), B operand = activations (cols = m),
+//      so every accumulator register holds 32 consecutive m of one oc row and
+//      the NCDHW store is contiguous along w.
+//
+//  wgrad GEMM    R[dc, j] = sum_m  D[dc, m] * G[j, m]          (weight gradients)
+//      dc = channel of the densely indexed tensor, j = (gathered channel, tap),
+//      reduction over all positions m, split over blockIdx.y into slabs that a
+//      second kernel sums in a fixed order (bitwise reproducible, no atomics).
+//
+// fp32 MFMA runs at the vector rate (157 TFLOP/s peak, 1/16 of bf16), so the
+// kernel is matrix-pipe bound with a large VALU / LDS / HBM margin: staging is
+// plain global -> VGPR -> LDS with one barrier per 16-deep K step and tables
+// (KEntry) carry all index arithmetic so one kernel serves every geometry.
+#include "dcv_common.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace dcv {
+
+thread_local char g_err[512] = {0};
+std::atomic<uint64_t> g_launches{0};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// one row of the K (gather) or J (wgrad) index table
+struct KEntry {
+    int32_t x_off;    // element offset added to the thread's base: chan*sc + tap deltas
+    uint32_t tapsel;  // per-dim tap bits: 1<<ud | 1<<(8+uh) | 1<<(16+uw); bit 31 = padding row
+    int32_t w_off;    // element offset of this (channel, tap) inside the weight tensor
+    int32_t pad;
+};
+
+struct DimTaps {
+    int32_t n;          // taps along this dim (<= 8)
+    int32_t mul, base;  // gathered position = o * mul + base + delta[u]
+    int32_t size;       // extent of the gathered tensor along this dim
+    int32_t delta[8];
+};
+
+struct GatherArgs {
+    const float* x;
+    float* y;
+    const float* wp;
+    const KEntry* ktab;
+    int32_t M, OC, OCp, KIT;     // positions, out channels, packed pitch, 16-row K iterations
+    FastDiv div_sp, div_hw, div_w;  // m -> (n, od, oh, ow): by OD*OH*OW, OH*OW, OW
+    int32_t OD, OH, OW, pad0;
+    DimTaps td, th, tw;
+    int64_t x_sn;
+    int32_t x_sd, x_sh, x_sw, pad1;
+    int64_t y_sn, y_sc, y_sd, y_sh, y_sw, y_off;
+    int32_t act, accumulate;
+    float slope, pad2;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == DCV_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    if (act == DCV_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t dim_mask(const DimTaps& t, int o, int shift) {
+    uint32_t m = 0;
+    const int p0 = o * t.mul + t.base;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u < t.n) {
+            const int p = p0 + t.delta[u];
+            if ((unsigned)p < (unsigned)t.size) m |= 1u << (shift + u);
+        }
+    }
+    return m;
+}
+
+// --------------------------------------------------------------------------- //
+// gather GEMM.  Block = 256 threads = 4 waves laid out WOC x WM; each wave owns
+// TOC x TM MFMA tiles of 32x32.  BN = 32*TOC*WOC output channels, BM = 32*TM*WM
+// positions, K step 16.
+// --------------------------------------------------------------------------- //
+template <int TOC, int TM, int WOC, int WM>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
+    constexpr int BN = 32 * TOC * WOC;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int XPT = 16 * BM / 256;        // gathered elements per thread per K step
+    constexpr int KSTEP = 256 / BM > 0 ? 256 / BM : 1;  // row stride between a thread's elements
+    static_assert(WOC * WM == 4, "4 waves");
+    static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
+    constexpr int WF4 = 16 * BN / 4;          // float4s in one W tile
+    constexpr int WPT = (WF4 + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float Xs[2][16][BM];
+    __shared__ __attribute__((aligned(16))) float Ws[2][16][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int woc = wave / WM, wm = wave % WM;
+
+    const int tiles_oc = a.OCp / BN;
+    const int oc_t = blockIdx.x % tiles_oc;
+    const int m_t = blockIdx.x / tiles_oc;
+    const int oc0 = oc_t * BN;
+    const int m0 = m_t * BM;
+
+    // sample index of the block's first position: all 32-bit offsets are relative to it
+    const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
+    const float* __restrict__ xblk = a.x + (int64_t)n0 * a.x_sn;
+
+    // ---- this thread's gather column ----
+    const int lm = tid % BM;
+    const int ksub = __builtin_amdgcn_readfirstlane(tid / BM);
+    int xbase = 0;
+    uint32_t vmask = 0;
+    {
+        const int m = m0 + lm;
+        if (m < a.M) {
+            const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+            uint32_t r = (uint32_t)m - n * a.div_sp.div;
+            const uint32_t od = fdiv(r, a.div_hw);
+            r -= od * a.div_hw.div;
+            const uint32_t oh = fdiv(r, a.div_w);
+            const uint32_t ow = r - oh * a.div_w.div;
+            vmask = dim_mask(a.td, (int)od, 0) | dim_mask(a.th, (int)oh, 8) | dim_mask(a.tw, (int)ow, 16);
+            xbase = (int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd +
+                    ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw;
+        }
+    }
+
+    f32x16 acc[TOC][TM];
+#pragma unroll
+    for (int i = 0; i < TOC; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float xv[XPT];
+    float4 wv[WPT];
+
+    auto load_tile = [&](int it) {
+        const KEntry* __restrict__ kt = a.ktab + it * 16;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const KEntry e = kt[ksub + KSTEP * i];
+            const bool ok = (vmask & e.tapsel) == e.tapsel;
+            const int off = ok ? xbase + e.x_off : 0;
+            const float v = xblk[off];
+            xv[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int f = tid + 256 * j;
+            if (WF4 % 256 == 0 || f < WF4) {
+                const int row = f / (BN / 4), c4 = f % (BN / 4);
+                wv[j] = *reinterpret_cast<const float4*>(a.wp + (int64_t)(it * 16 + row) * a.OCp + oc0 + c4 * 4);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) Xs[buf][ksub + KSTEP * i][lm] = xv[i];
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int f = tid + 256 * j;
+            if (WF4 % 256 == 0 || f < WF4) {
+                const int row = f / (BN / 4), c4 = f % (BN / 4);
+                *reinterpret_cast<float4*>(&Ws[buf][row][c4 * 4]) = wv[j];
+            }
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int it = 0; it < a.KIT; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < a.KIT) load_tile(it + 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int k = 2 * ks + lhi;
+            float af[TOC], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TOC; ++i) af[i] = Ws[buf][k][(woc * TOC + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) bf[j] = Xs[buf][k][(wm * TM + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < a.KIT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][r] -> oc = .. + (r&3) + 8*(r>>2) + 4*lhi, m = .. + l31 ----
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 32 + l31;
+        if (m >= a.M) continue;
+        const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+        uint32_t r0 = (uint32_t)m - n * a.div_sp.div;
+        const uint32_t od = fdiv(r0, a.div_hw);
+        r0 -= od * a.div_hw.div;
+        const uint32_t oh = fdiv(r0, a.div_w);
+        const uint32_t ow = r0 - oh * a.div_w.div;
+        float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+#pragma unroll
+        for (int i = 0; i < TOC; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (oc < a.OC) {
+                    float v = acc[i][j][r];
+                    float* p = yb + (int64_t)oc * a.y_sc;
+                    if (a.accumulate) v += *p;
+                    *p = apply_act(v, a.act, a.slope);
+                }
+            }
+        }
+    }
+}
+
+// Wp[k][oc] = w[oc * ws_o + ktab[k].w_off]   (zero for padding rows / channels)
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, const KEntry* __restrict__ ktab,
+                                    int K16, int OC, int OCp, int64_t ws_o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)K16 * OCp) return;
+    const int k = (int)(i / OCp), oc = (int)(i % OCp);
+    const KEntry e = ktab[k];
+    float v = 0.f;
+    if (oc < OC && !(e.tapsel >> 31)) v = w[(int64_t)oc * ws_o + e.w_off];
+    wp[i] = v;
+}
+
+// --------------------------------------------------------------------------- //
+// wgrad GEMM.  R[dc, j] = sum_m D[dc, m] G[j, m].  Block tile BD x BJ, reduction
+// step 32 positions, blockIdx.y = split of the position range.
+// --------------------------------------------------------------------------- //
+struct WgradArgs {
+    const float* dptr;
+    const float* gptr;
+    float* slab;
+    const KEntry* jtab;
+    int32_t M, DC, J, DCp, Jp, chunk, pad0, pad1;
+    FastDiv div_sp, div_hw, div_w;
+    DimTaps td, th, tw;
+    int64_t d_sn, d_sc, d_sd, d_sh, d_sw;
+    int64_t g_sn, g_sd, g_sh, g_sw;
+};
+
+template <int TD, int TJ, int WD, int WJ>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
+    constexpr int BD = 32 * TD * WD;
+    constexpr int BJ = 32 * TJ * WJ;
+    constexpr int DPT = BD / 8, JPT = BJ / 8;  // elements per thread per step
+    static_assert(WD * WJ == 4, "4 waves");
+    __shared__ float Ds[2][32][BD + 1];
+    __shared__ float Gs[2][32][BJ + 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wave / WJ, wj = wave % WJ;
+    const int tiles_d = a.DCp / BD;
+    const int d_t = blockIdx.x % tiles_d, j_t = blockIdx.x / tiles_d;
+    const int d0 = d_t * BD, j0 = j_t * BJ;
+    const int ml = tid & 31, sub = tid >> 5;
+
+    const int m_begin = blockIdx.y * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int nit = (m_end > m_begin) ? (m_end - m_begin + 31) / 32 : 0;
+
+    // this thread's J rows are fixed for the whole reduction
+    int32_t goff[JPT];
+    uint32_t gsel[JPT];
+#pragma unroll
+    for (int i = 0; i < JPT; ++i) {
+        const int j = j0 + sub + 8 * i;
+        if (j < a.J) {
+            const KEntry e = a.jtab[j];
+            goff[i] = e.x_off;
+            gsel[i] = e.tapsel;
+        } else {
+            goff[i] = 0;
+            gsel[i] = 1u << 31;
+        }
+    }
+
+    f32x16 acc[TD][TJ];
+#pragma unroll
+    for (int i = 0; i < TD; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float dv[DPT], gv[JPT];
+
+    auto load_tile = [&](int it) {
+        const int m = m_begin + it * 32 + ml;
+        const bool mok = m < m_end;
+        const int mm = mok ? m : m_begin;
+        const uint32_t n = fdiv((uint32_t)mm, a.div_sp);
+        uint32_t r = (uint32_t)mm - n * a.div_sp.div;
+        const uint32_t pd = fdiv(r, a.div_hw);
+        r -= pd * a.div_hw.div;
+        const uint32_t ph = fdiv(r, a.div_w);
+        const uint32_t pw = r - ph * a.div_w.div;
+        const float* __restrict__ dp = a.dptr + (int64_t)n * a.d_sn + (int64_t)pd * a.d_sd + (int64_t)ph * a.d_sh + (int64_t)pw * a.d_sw;
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) {
+            const int dc = d0 + sub + 8 * i;
+            const bool ok = mok && dc < a.DC;
+            const float v = dp[ok ? (int64_t)dc * a.d_sc : 0];
+            dv[i] = ok ? v : 0.f;
+        }
+        const uint32_t vmask = mok ? (dim_mask(a.td, (int)pd, 0) | dim_mask(a.th, (int)ph, 8) | dim_mask(a.tw, (int)pw, 16)) : 0u;
+        const int64_t gb = (int64_t)n * a.g_sn + (int64_t)((int)pd * a.td.mul + a.td.base) * a.g_sd +
+                           (int64_t)((int)ph * a.th.mul + a.th.base) * a.g_sh + (int64_t)((int)pw * a.tw.mul + a.tw.base) * a.g_sw;
+#pragma unroll
+        for (int i = 0; i < JPT; ++i) {
+            const bool ok = (vmask & gsel[i]) == gsel[i];
+            const float v = a.gptr[ok ? gb + goff[i] : 0];
+            gv[i] = ok ? v : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < DPT; ++i) Ds[buf][ml][sub + 8 * i] = dv[i];
+#pragma unroll
+        for (int i = 0; i < JPT; ++i) Gs[buf][ml][sub + 8 * i] = gv[i];
+    };
+
+    if (nit > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int it = 0; it < nit; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nit) load_tile(it + 1);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int k = 2 * ks + lhi;
+            float af[TD], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TD; ++i) af[i] = Ds[buf][k][(wd * TD + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = Gs[buf][k][(wj * TJ + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TD; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (it + 1 < nit) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* __restrict__ out = a.slab + (int64_t)blockIdx.y * a.DCp * a.Jp;
+#pragma unroll
+    for (int i = 0; i < TD; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dc = d0 + (wd * TD + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int jj = j0 + (wj * TJ + j) * 32 + l31;
+                out[(int64_t)dc * a.Jp + jj] = acc[i][j][r];
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)DC * J) return;
+    const int dc = (int)(i / J), j = (int)(i % J);
+    const int64_t stride = (int64_t)DCp * Jp;
+    const float* p = slab + (int64_t)dc * Jp + j;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += p[k * stride];
+    dw[i] = s;
+}
+
+// --------------------------------------------------------------------------- //
+// host side: plans (index tables cached on the device per distinct geometry)
+// --------------------------------------------------------------------------- //
+struct DevTable {
+    KEntry* dev = nullptr;
+    int rows = 0;
+};
+
+static std::mutex g_plan_mu;
+static std::map<std::string, DevTable> g_tables;
+
+static int get_table(const std::string& key, const std::vector<KEntry>& host, DevTable* out) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) {
+        *out = it->second;
+        return DCV_OK;
+    }
+    DevTable t;
+    t.rows = (int)host.size();
+    DCV_HIP_CHECK(hipMalloc((void**)&t.dev, host.size() * sizeof(KEntry)));
+    DCV_HIP_CHECK(hipMemcpy(t.dev, host.data(), host.size() * sizeof(KEntry), hipMemcpyHostToDevice));
+    g_tables[key] = t;
+    *out = t;
+    return DCV_OK;
+}
+
+// One launch of the gather GEMM (one stride-parity class).
+struct GatherClass {
+    // per dim (d,h,w): sub-grid extent, output multiplier/offset, taps
+    int o_ext[3];
+    int out_mul[3], out_off[3];
+    DimTaps taps[3];
+    std::vector<int> tap_k[3];  // filter index along the dim for each tap u
+};
+
+struct TileCfg {
+    int bn, bm;
+};
+
+static TileCfg pick_gather_tile(int OC) {
+    if (OC > 64) return {128, 128};
+    if (OC > 32) return {64, 256};
+    return {32, 256};
+}
+
+template <int TOC, int TM, int WOC, int WM>
+static void launch_gather(const GatherArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM>), dim3(grid), dim3(256), 0, s, a);
+}
+
+// The generic driver: reduce over `RC` channels of tensor `x` (dims xd) into `OC`
+// channels of tensor `y` (dims yd); classes describe position/tap relations;
+// weight element (oc, rc, kd, kh, kw) lives at oc*ws_o + rc*ws_r + ((kd*KH)+kh)*KW+kw.
+static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_dims5& yd, const float* w,
+                      int RC, int OC, int64_t ws_o, int64_t ws_r, int KH, int KW,
+                      const std::vector<GatherClass>& classes, int act, float slope, int accumulate,
+                      void* ws, size_t ws_bytes, hipStream_t stream, const char* tag) {
+    const TileCfg tc = pick_gather_tile(OC);
+    const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
+    size_t ws_off = 0;
+    int ci = 0;
+    for (const GatherClass& c : classes) {
+        ++ci;
+        const int T = c.taps[0].n * c.taps[1].n * c.taps[2].n;
+        if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+        const int64_t K = (int64_t)RC * T;
+        const int KIT = (int)((K + 15) / 16);
+        const int64_t M64 = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+        if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
+        // ---- K table (cached) ----
+        std::string key(tag);
+        {
+            char buf[512];
+            int nn = snprintf(buf, sizeof(buf), "|g|%d|%d|%lld|%lld|%d|%d|%lld|%lld|%lld|%lld|", RC, OC, (long long)ws_o, (long long)ws_r, KH, KW,
+                              (long long)xd.sc, (long long)xd.sd, (long long)xd.sh, (long long)xd.sw);
+            key.append(buf, nn);
+            for (int d = 0; d < 3; ++d) {
+                nn = snprintf(buf, sizeof(buf), "%d:", c.taps[d].n);
+                key.append(buf, nn);
+                for (int u = 0; u < c.taps[d].n; ++u) {
+                    nn = snprintf(buf, sizeof(buf), "%d,%d;", c.taps[d].delta[u], c.tap_k[d][u]);
+                    key.append(buf, nn);
+                }
+            }
+        }
+        DevTable tab;
+        {
+            std::lock_guard<std::mutex> lk(g_plan_mu);
+            auto it = g_tables.find(key);
+            if (it != g_tables.end()) tab = it->second;
+        }
+        if (!tab.dev) {
+            std::vector<KEntry> host((size_t)KIT * 16);
+            size_t k = 0;
+            for (int rc = 0; rc < RC; ++rc)
+                for (int ud = 0; ud < c.taps[0].n; ++ud)
+                    for (int uh = 0; uh < c.taps[1].n; ++uh)
+                        for (int uw = 0; uw < c.taps[2].n; ++uw) {
+                            KEntry e;
+                            const int64_t xo = (int64_t)rc * xd.sc + (int64_t)c.taps[0].delta[ud] * xd.sd +
+                                               (int64_t)c.taps[1].delta[uh] * xd.sh + (int64_t)c.taps[2].delta[uw] * xd.sw;
+                            if (xo > INT32_MAX || xo < INT32_MIN) return fail(DCV_EUNSUPPORTED, "%s: tensor too large for 32-bit offsets", tag);
+                            e.x_off = (int32_t)xo;
+                            e.tapsel = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
+                            e.w_off = (int32_t)(rc * ws_r + ((int64_t)c.tap_k[0][ud] * KH + c.tap_k[1][uh]) * KW + c.tap_k[2][uw]);
+                            e.pad = 0;
+                            host[k++] = e;
+                        }
+            for (; k < host.size(); ++k) host[k] = KEntry{0, 1u << 31, 0, 0};
+            int rc_ = get_table(key, host, &tab);
+            if (rc_ != DCV_OK) return rc_;
+        }
+        // ---- pack weights ----
+        const size_t wp_bytes = align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
+        if (ws_off + wp_bytes > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, ws_off + wp_bytes, ws_bytes);
+        float* wp = reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off);
+        ws_off += wp_bytes;
+        {
+            const int64_t tot = (int64_t)KIT * 16 * OCp;
+            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, wp, tab.dev, KIT * 16, OC, OCp, ws_o);
+            DCV_LAUNCH_CHECK();
+        }
+        // ---- GEMM ----
+        GatherArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x;
+        a.y = y;
+        a.wp = wp;
+        a.ktab = tab.dev;
+        a.M = (int)M64;
+        a.OC = OC;
+        a.OCp = OCp;
+        a.KIT = KIT;
+        a.OD = c.o_ext[0];
+        a.OH = c.o_ext[1];
+        a.OW = c.o_ext[2];
+        a.div_sp = make_fastdiv((uint32_t)(c.o_ext[0] * c.o_ext[1] * c.o_ext[2]));
+        a.div_hw = make_fastdiv((uint32_t)(c.o_ext[1] * c.o_ext[2]));
+        a.div_w = make_fastdiv((uint32_t)c.o_ext[2]);
+        a.td = c.taps[0];
+        a.th = c.taps[1];
+        a.tw = c.taps[2];
+        a.x_sn = xd.sn;
+        // per-block 32-bit offset budget: samples touched by one M tile
+        {
+            const int64_t per = (int64_t)c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+            const int64_t span = (tc.bm / per + 2) * (xd.sn < 0 ? -xd.sn : xd.sn) + (int64_t)RC * (xd.sc < 0 ? -xd.sc : xd.sc);
+            if (span >= (1ll << 31) || xd.sd > INT32_MAX / 64 || xd.sh > INT32_MAX / 64 || xd.sw > INT32_MAX / 64)
+                return fail(DCV_EUNSUPPORTED, "%s: input too large for 32-bit block offsets", tag);
+        }
+        a.x_sd = (int32_t)xd.sd;
+        a.x_sh = (int32_t)xd.sh;
+        a.x_sw = (int32_t)xd.sw;
+        a.y_sn = yd.sn;
+        a.y_sc = yd.sc;
+        a.y_sd = yd.sd * c.out_mul[0];
+        a.y_sh = yd.sh * c.out_mul[1];
+        a.y_sw = yd.sw * c.out_mul[2];
+        a.y_off = yd.sd * c.out_off[0] + yd.sh * c.out_off[1] + yd.sw * c.out_off[2];
+        a.act = act;
+        a.slope = slope;
+        a.accumulate = accumulate;
+        const int grid = (OCp / tc.bn) * ((a.M + tc.bm - 1) / tc.bm);
+        if (tc.bn == 128) launch_gather<2, 2, 2, 2>(a, grid, stream);
+        else if (tc.bn == 64) launch_gather<2, 2, 1, 4>(a, grid, stream);
+        else launch_gather<1, 2, 1, 4>(a, grid, stream);
+        DCV_LAUNCH_CHECK();
+    }
+    return DCV_OK;
+}
+
+static size_t gather_ws_bytes(int RC, int OC, const std::vector<GatherClass>& classes) {
+    const TileCfg tc = pick_gather_tile(OC);
+    const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
+    size_t tot = 0;
+    for (const GatherClass& c : classes) {
+        const int T = c.taps[0].n * c.taps[1].n * c.taps[2].n;
+        const int64_t K = (int64_t)RC * T;
+        tot += align_up((size_t)((K + 15) / 16) * 16 * OCp * sizeof(float), 256);
+    }
+    return tot + 256;
+}
+
+// "direct" relation: gathered position = o*stride - pad + k  (conv fprop, convT dgrad)
+static std::vector<GatherClass> direct_classes(const int k[3], const int s[3], const int p[3], const int o_ext[3], const int in_ext[3]) {
+    GatherClass c;
+    for (int d = 0; d < 3; ++d) {
+        c.o_ext[d] = o_ext[d];
+        c.out_mul[d] = 1;
+        c.out_off[d] = 0;
+        DimTaps& t = c.taps[d];
+        memset(&t, 0, sizeof(t));
+        t.n = k[d];
+        t.mul = s[d];
+        t.base = -p[d];
+        t.size = in_ext[d];
+        for (int u = 0; u < k[d]; ++u) {
+            t.delta[u] = u;
+            c.tap_k[d].push_back(u);
+        }
+    }
+    return {c};
+}
+
+// "scatter" relation: produced position i receives tap k from gathered position
+// o = (i + p - k)/s when divisible (conv dgrad, convT fprop).  One class per
+// residue of i mod s in every dim.
+static std::vector<GatherClass> scatter_classes(const int k[3], const int s[3], const int p[3], const int out_ext[3], const int in_ext[3]) {
+    std::vector<GatherClass> out;
+    for (int cd = 0; cd < s[0]; ++cd)
+        for (int ch = 0; ch < s[1]; ++ch)
+            for (int cw = 0; cw < s[2]; ++cw) {
+                const int cls[3] = {cd, ch, cw};
+                GatherClass c;
+                for (int d = 0; d < 3; ++d) {
+                    c.o_ext[d] = (out_ext[d] - cls[d] + s[d] - 1) / s[d];
+                    c.out_mul[d] = s[d];
+                    c.out_off[d] = cls[d];
+                    DimTaps& t = c.taps[d];
+                    memset(&t, 0, sizeof(t));
+                    const int k0 = (cls[d] + p[d]) % s[d];
+                    const int q = (cls[d] + p[d] - k0) / s[d];
+                    t.mul = 1;
+                    t.base = q;
+                    t.size = in_ext[d];
+                    int u = 0;
+                    for (int kk = k0; kk < k[d]; kk += s[d], ++u) {
+                        t.delta[u] = -u;
+                        c.tap_k[d].push_back(kk);
+                    }
+                    t.n = u;
+                }
+                out.push_back(c);
+            }
+    return out;
+}
+
+static int check_geom(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, const char* tag) {
+    if (!g || !x || !y) return fail(DCV_EINVAL, "%s: null descriptor", tag);
+    if (g->kd < 1 || g->kh < 1 || g->kw < 1 || g->kd > 8 || g->kh > 8 || g->kw > 8) return fail(DCV_EINVAL, "%s: filter size out of range", tag);
+    if (g->sd < 1 || g->sh < 1 || g->sw < 1 || g->pd < 0 || g->ph < 0 || g->pw < 0) return fail(DCV_EINVAL, "%s: bad stride/padding", tag);
+    if (x->c != g->cin || y->c != g->cout || x->n != y->n) return fail(DCV_EINVAL, "%s: channel/batch mismatch (x.c %d cin %d, y.c %d cout %d, n %d/%d)", tag, x->c, g->cin, y->c, g->cout, x->n, y->n);
+    const int xi[3] = {x->d, x->h, x->w}, yo[3] = {y->d, y->h, y->w};
+    const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
+    for (int d = 0; d < 3; ++d) {
+        const int expect = g->transposed ? (xi[d] - 1) * s[d] - 2 * p[d] + k[d] : (xi[d] + 2 * p[d] - k[d]) / s[d] + 1;
+        if (expect != yo[d] || expect < 1) return fail(DCV_EINVAL, "%s: output extent mismatch in dim %d (%d vs %d)", tag, d, yo[d], expect);
+    }
+    if (x->n < 1 || x->c < 1 || y->c < 1) return fail(DCV_EINVAL, "%s: empty tensor", tag);
+    return DCV_OK;
+}
+
+// ---- wgrad driver ---------------------------------------------------------- //
+struct WgradTile {
+    int bd, bj;
+};
+static WgradTile pick_wgrad_tile(int DC, int J) {
+    if (DC > 64) return (J > 64) ? WgradTile{128, 128} : WgradTile{128, 64};
+    if (DC > 32) return (J > 128) ? WgradTile{64, 256} : WgradTile{64, 128};
+    return (J > 128) ? WgradTile{32, 256} : WgradTile{32, 128};
+}
+
+static int wgrad_splits(int64_t M, int tiles) {
+    // aim for ~1024 blocks, at least 8 reduction steps (256 positions) per block
+    int64_t want = (1024 + tiles - 1) / tiles;
+    int64_t maxs = (M + 255) / 256;
+    int64_t s = want < maxs ? want : maxs;
+    if (s < 1) s = 1;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+
+template <int TD, int TJ, int WD, int WJ>
+static void launch_wgrad(const WgradArgs& a, int gx, int gy, hipStream_t s) {
+    hipLaunchKernelGGL((wgrad_gemm_kernel<TD, TJ, WD, WJ>), dim3(gx, gy), dim3(256), 0, s, a);
+}
+
+// dense tensor D (dims dd, channels DC), gathered tensor G (dims gd, channels GC):
+// R[dc][gc][kd][kh][kw] = sum_{n,pos} D[n,dc,pos] * G[n,gc,pos*s - p + k]
+static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R,
+                     const int k[3], const int s[3], const int p[3], void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
+                     size_t* need_only) {
+    const int DC = dd.c, GC = gd.c;
+    const int T = k[0] * k[1] * k[2];
+    const int64_t J64 = (int64_t)GC * T;
+    if (J64 >= (1 << 30)) return fail(DCV_EUNSUPPORTED, "%s: J too large", tag);
+    const int J = (int)J64;
+    const WgradTile tc = pick_wgrad_tile(DC, J);
+    const int DCp = (DC + tc.bd - 1) / tc.bd * tc.bd;
+    const int Jp = (J + tc.bj - 1) / tc.bj * tc.bj;
+    const int64_t M64 = (int64_t)dd.n * dd.d * dd.h * dd.w;
+    if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
+    const int tiles = (DCp / tc.bd) * (Jp / tc.bj);
+    const int S = wgrad_splits(M64, tiles);
+    int64_t chunk = (M64 + S - 1) / S;
+    chunk = (chunk + 31) / 32 * 32;
+    const int S2 = (int)((M64 + chunk - 1) / chunk);
+    const size_t need = align_up((size_t)S2 * DCp * Jp * sizeof(float), 256);
+    if (need_only) {
+        *need_only = need + 256;
+        return DCV_OK;
+    }
+    if (need > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, need, ws_bytes);
+
+    char kb[512];
+    int nn = snprintf(kb, sizeof(kb), "%s|w|%d|%d,%d,%d|%lld|%lld|%lld|%lld", tag, GC, k[0], k[1], k[2], (long long)gd.sc, (long long)gd.sd, (long long)gd.sh, (long long)gd.sw);
+    std::string key(kb, nn);
+    DevTable tab;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_tables.find(key);
+        if (it != g_tables.end()) tab = it->second;
+    }
+    if (!tab.dev) {
+        std::vector<KEntry> host((size_t)J);
+        size_t q = 0;
+        for (int gc = 0; gc < GC; ++gc)
+            for (int ud = 0; ud < k[0]; ++ud)
+                for (int uh = 0; uh < k[1]; ++uh)
+                    for (int uw = 0; uw < k[2]; ++uw) {
+                        KEntry e;
+                        const int64_t xo = (int64_t)gc * gd.sc + (int64_t)ud * gd.sd + (int64_t)uh * gd.sh + (int64_t)uw * gd.sw;
+                        if (xo > INT32_MAX) return fail(DCV_EUNSUPPORTED, "%s: tensor too large for 32-bit offsets", tag);
+                        e.x_off = (int32_t)xo;
+                        e.tapsel = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
+                        e.w_off = 0;
+                        e.pad = 0;
+                        host[q++] = e;
+                    }
+        int rc_ = get_table(key, host, &tab);
+        if (rc_ != DCV_OK) return rc_;
+    }
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dptr = D;
+    a.gptr = G;
+    a.slab = static_cast<float*>(ws);
+    a.jtab = tab.dev;
+    a.M = (int)M64;
+    a.DC = DC;
+    a.J = J;
+    a.DCp = DCp;
+    a.Jp = Jp;
+    a.chunk = (int)chunk;
+    a.div_sp = make_fastdiv((uint32_t)(dd.d * dd.h * dd.w));
+    a.div_hw = make_fastdiv((uint32_t)(dd.h * dd.w));
+    a.div_w = make_fastdiv((uint32_t)dd.w);
+    const int gext[3] = {gd.d, gd.h, gd.w};
+    DimTaps* ts[3] = {&a.td, &a.th, &a.tw};
+    for (int d = 0; d < 3; ++d) {
+        ts[d]->n = k[d];
+        ts[d]->mul = s[d];
+        ts[d]->base = -p[d];
+        ts[d]->size = gext[d];
+        for (int u = 0; u < k[d]; ++u) ts[d]->delta[u] = u;
+    }
+    a.d_sn = dd.sn; a.d_sc = dd.sc; a.d_sd = dd.sd; a.d_sh = dd.sh; a.d_sw = dd.sw;
+    a.g_sn = gd.sn; a.g_sd = gd.sd; a.g_sh = gd.sh; a.g_sw = gd.sw;
+    if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
+    else if (tc.bd == 128 && tc.bj == 64) launch_wgrad<2, 1, 2, 2>(a, tiles, S2, stream);
+    else if (tc.bd == 64 && tc.bj == 256) launch_wgrad<2, 2, 1, 4>(a, tiles, S2, stream);
+    else if (tc.bd == 64 && tc.bj == 128) launch_wgrad<2, 1, 1, 4>(a, tiles, S2, stream);
+    else if (tc.bd == 32 && tc.bj == 256) launch_wgrad<1, 2, 1, 4>(a, tiles, S2, stream);
+    else launch_wgrad<1, 1, 1, 4>(a, tiles, S2, stream);
+    DCV_LAUNCH_CHECK();
+    const int64_t tot = (int64_t)DC * J;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+}  // namespace dcv
+
+using namespace dcv;
+
+extern "C" {
+
+const char* dcv_last_error(void) { return g_err; }
+int dcv_version(void) { return 1; }
+uint64_t dcv_launch_count(void) { return g_launches.load(); }
+
+// which: 0 forward, 1 backward-data, 2 backward-weight
+static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, const dcv_dims5* xd, const float* w,
+                         float* out, const dcv_dims5* yd, int act, float slope, int accumulate,
+                         void* ws, size_t ws_bytes, void* stream, size_t* need_only) {
+    // xd = module input dims, yd = module output dims, always.
+    int rc = check_geom(g, xd, yd, "conv");
+    if (rc != DCV_OK) return rc;
+    const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
+    const int xi[3] = {xd->d, xd->h, xd->w}, yo[3] = {yd->d, yd->h, yd->w};
+    const int T = k[0] * k[1] * k[2];
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // forward of conv / backward-data of convT : direct gather from the module INPUT side tensor
+    const bool direct = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
+    if (which == 0 || which == 1) {
+        // src tensor dims / dst tensor dims
+        const dcv_dims5& src = (which == 0) ? *xd : *yd;
+        const dcv_dims5& dst = (which == 0) ? *yd : *xd;
+        const int RC = src.c, OC = dst.c;
+        std::vector<GatherClass> cls;
+        int64_t ws_o, ws_r;
+        if (direct) {
+            // conv fprop: src = x (gathered at o*s-p+k), dst = y.  weight (cout, cin, T): oc = cout
+            // convT dgrad: src = dy (module output), dst = dx; dx[i] = sum dy[i*s-p+k] w[ci,co,k]: weight (cin, cout, T): oc = cin
+            const int* o_ext = (which == 0) ? yo : xi;
+            const int* in_ext = (which == 0) ? xi : yo;
+            cls = direct_classes(k, s, p, o_ext, in_ext);
+            ws_o = (int64_t)RC * T;
+            ws_r = T;
+        } else {
+            // conv dgrad: src = dy, dst = dx, weight (cout, cin, T): oc = cin -> ws_o = T, ws_r = cin*T
+            // convT fprop: src = x, dst = y, weight (cin, cout, T): oc = cout -> ws_o = T, ws_r = cout*T
+            const int* out_ext = (which == 0) ? yo : xi;
+            const int* in_ext = (which == 0) ? xi : yo;
+            cls = scatter_classes(k, s, p, out_ext, in_ext);
+            ws_o = T;
+            ws_r = (int64_t)OC * T;
+        }
+        if (need_only) {
+            *need_only = gather_ws_bytes(RC, OC, cls);
+            return DCV_OK;
+        }
+        if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
+        return run_gather(a_, src, out, dst, w, RC, OC, ws_o, ws_r, k[1], k[2], cls, act, slope, accumulate, ws, ws_bytes, st,
+                          which == 0 ? (g->transposed ? "convT_fwd" : "conv_fwd") : (g->transposed ? "convT_bwd_data" : "conv_bwd_data"));
+    }
+    return fail(DCV_EINVAL, "conv: bad dispatch");
+}
+
+size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
+    size_t need = 0;
+    if (which == 2) {
+        if (check_geom(g, x, y, "conv_ws") != DCV_OK) return 0;
+        const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
+        const dcv_dims5& D = g->transposed ? *x : *y;
+        const dcv_dims5& G = g->transposed ? *y : *x;
+        if (run_wgrad(nullptr, D, nullptr, G, nullptr, k, s, p, nullptr, 0, nullptr, "ws", &need) != DCV_OK) return 0;
+        return need;
+    }
+    if (conv_dispatch(which, g, nullptr, x, nullptr, nullptr, y, 0, 0.f, 0, nullptr, 0, nullptr, &need) != DCV_OK) return 0;
+    return need;
+}
+
+int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
+                     int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+    return conv_dispatch(0, g, x, xd, w, y, yd, act, slope, 0, ws, ws_bytes, stream, nullptr);
+}
+
+int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd,
+                           int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
+int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd,
+                             float* dw, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_geom(g, xd, dyd, "conv_bwd_weight");
+    if (rc != DCV_OK) return rc;
+    if (!x || !dy || !dw || !ws) return fail(DCV_EINVAL, "conv_bwd_weight: null pointer");
+    const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
+    // conv : dw[co][ci][k] = sum dy[n,co,o] x[n,ci,o*s-p+k]  -> dense = dy, gathered = x
+    // convT: dw[ci][co][k] = sum x[n,ci,i] dy[n,co,i*s-p+k]  -> dense = x,  gathered = dy
+    if (!g->transposed)
+        return run_wgrad(dy, *dyd, x, *xd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "conv_bwd_weight", nullptr);
+    return run_wgrad(x, *xd, dy, *dyd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "convT_bwd_weight", nullptr);
+}
+
+}  // extern "C"

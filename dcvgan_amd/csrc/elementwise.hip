@@ -1,0 +1,766 @@
+// HBM-bound kernels of the DCVGAN step for gfx950: BatchNorm (+Dropout2d +activation)
+// forward/backward, activations, axpby / strided copy, Philox noise, GAN losses,
+// GRU recurrence, Adam.  All work on NCDHW views: a "row" is one (n, c, d) plane
+// of H*W contiguous floats (vectorised 16 B per lane); views whose (h, w) plane is
+// not contiguous fall back to rows of one element.
+#include "dcv_common.h"
+
+namespace dcv {
+
+struct RowView {
+    int64_t sn, sc, sd, sh, sw;
+};
+
+// rows = N*C*D*(H*W/inner); inner = contiguous run (H*W or 1)
+struct RowMap {
+    int32_t N, C, D, H, W;
+    int32_t inner;   // contiguous run length in elements
+    int32_t vec;     // 4 if inner % 4 == 0 and all views 16-B friendly, else 1
+    int32_t gpr;     // groups (of vec elements) per row
+    FastDiv div_gpr, div_cd, div_d, div_w;  // g -> row, row -> n, (c,d); tail -> (h,w) when inner == 1
+    int64_t groups;
+};
+
+static bool plane_contig(const dcv_dims5& v) { return (v.w == 1 || v.sw == 1) && (v.h == 1 || v.sh == v.w); }
+
+static RowMap make_rowmap(const dcv_dims5& shape, const dcv_dims5* const* views, int nviews, const void* const* ptrs) {
+    RowMap m;
+    memset(&m, 0, sizeof(m));
+    m.N = shape.n; m.C = shape.c; m.D = shape.d; m.H = shape.h; m.W = shape.w;
+    bool contig = true;
+    for (int i = 0; i < nviews; ++i) contig = contig && plane_contig(*views[i]);
+    const int hw = shape.h * shape.w;
+    m.inner = contig ? hw : 1;
+    bool v4 = contig && (hw % 4 == 0);
+    if (v4)
+        for (int i = 0; i < nviews; ++i) {
+            const dcv_dims5& v = *views[i];
+            if ((v.sn % 4) || (v.sc % 4) || (v.sd % 4) || (reinterpret_cast<uintptr_t>(ptrs[i]) % 16)) v4 = false;
+        }
+    m.vec = v4 ? 4 : 1;
+    m.gpr = contig ? hw / m.vec : hw;  // when not contiguous: one group per element, "row" = (n,c,d)
+    m.div_gpr = make_fastdiv((uint32_t)m.gpr);
+    m.div_cd = make_fastdiv((uint32_t)(shape.c * shape.d));
+    m.div_d = make_fastdiv((uint32_t)shape.d);
+    m.div_w = make_fastdiv((uint32_t)shape.w);
+    m.groups = (int64_t)shape.n * shape.c * shape.d * m.gpr;
+    return m;
+}
+
+struct Pos {
+    int n, c, d, col;  // col: element offset inside the (h, w) plane (first of the group)
+    int h, w;
+};
+
+__device__ __forceinline__ Pos locate(const RowMap& m, uint32_t g) {
+    Pos p;
+    const uint32_t row = fdiv(g, m.div_gpr);
+    const uint32_t cg = g - row * m.div_gpr.div;
+    const uint32_t n = fdiv(row, m.div_cd);
+    const uint32_t cd = row - n * m.div_cd.div;
+    const uint32_t c = fdiv(cd, m.div_d);
+    p.n = (int)n; p.c = (int)c; p.d = (int)(cd - c * m.div_d.div);
+    p.col = (int)cg * m.vec;
+    if (m.inner == 1) {
+        const uint32_t h = fdiv(cg, m.div_w);
+        p.h = (int)h; p.w = (int)(cg - h * m.div_w.div);
+    } else {
+        p.h = 0; p.w = 0;
+    }
+    return p;
+}
+
+__device__ __forceinline__ int64_t offs(const RowMap& m, const RowView& v, const Pos& p) {
+    int64_t o = (int64_t)p.n * v.sn + (int64_t)p.c * v.sc + (int64_t)p.d * v.sd;
+    if (m.inner == 1) o += (int64_t)p.h * v.sh + (int64_t)p.w * v.sw;
+    else o += p.col;
+    return o;
+}
+
+static RowView rv(const dcv_dims5& d) { return RowView{d.sn, d.sc, d.sd, d.sh, d.sw}; }
+
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+    if (act == DCV_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    if (act == DCV_ACT_TANH) return tanhf(v);
+    return v;
+}
+// derivative evaluated from the OUTPUT y
+__device__ __forceinline__ float act_bwd_from_y(float y, int act, float slope) {
+    if (act == DCV_ACT_LEAKY) return y > 0.f ? 1.f : slope;
+    if (act == DCV_ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+static inline unsigned grid_for(int64_t groups) {
+    int64_t b = (groups + 255) / 256;
+    if (b > 8192) b = 8192;   // 256 CUs x 8 blocks x 4: grid-stride beyond
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------- //
+// generic unary / binary elementwise kernels
+// ------------------------------------------------------------------------- //
+template <int VEC, class F>
+__global__ __launch_bounds__(256) void ew_kernel(RowMap m, F f) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < m.groups; g += (int64_t)gridDim.x * 256) {
+        const Pos p = locate(m, (uint32_t)g);
+        f.template apply<VEC>(m, p);
+    }
+}
+
+template <class F>
+static int launch_ew(const RowMap& m, const F& f, hipStream_t s) {
+    if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "elementwise: tensor too large");
+    if (m.groups == 0) return DCV_OK;
+    if (m.vec == 4) hipLaunchKernelGGL((ew_kernel<4, F>), dim3(grid_for(m.groups)), dim3(256), 0, s, m, f);
+    else hipLaunchKernelGGL((ew_kernel<1, F>), dim3(grid_for(m.groups)), dim3(256), 0, s, m, f);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> { typedef float4 T; };
+template <> struct Vec<1> { typedef float T; };
+template <int VEC> __device__ __forceinline__ void ld(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else v[0] = *p;
+}
+template <int VEC> __device__ __forceinline__ void st(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else *p = v[0];
+}
+
+struct ActFwd {
+    const float* x; float* y; RowView xv, yv; int act; float slope;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float v[VEC];
+        ld<VEC>(x + offs(m, xv, p), v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = act_fwd(v[i], act, slope);
+        st<VEC>(y + offs(m, yv, p), v);
+    }
+};
+struct ActBwd {
+    const float* dy; const float* y; float* dx; RowView dyv, yv, dxv; int act; float slope;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float g[VEC], o[VEC];
+        ld<VEC>(dy + offs(m, dyv, p), g);
+        ld<VEC>(y + offs(m, yv, p), o);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) g[i] *= act_bwd_from_y(o[i], act, slope);
+        st<VEC>(dx + offs(m, dxv, p), g);
+    }
+};
+struct Axpby {
+    const float* x; const float* z; float* y; RowView xv, zv, yv; float a, b;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float u[VEC];
+        ld<VEC>(x + offs(m, xv, p), u);
+        if (z) {
+            float w[VEC];
+            ld<VEC>(z + offs(m, zv, p), w);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) u[i] = a * u[i] + b * w[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) u[i] = a * u[i];
+        }
+        st<VEC>(y + offs(m, yv, p), u);
+    }
+};
+
+// ------------------------------------------------------------------------- //
+// Philox4x32-10 + Box-Muller
+// ------------------------------------------------------------------------- //
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// 4 N(0,1) samples for 128-bit counter (idx, stream offset)
+__device__ __forceinline__ void normal4(uint64_t seed, uint64_t offset, uint64_t idx, float (&o)[4]) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float s = 2.3283064365386963e-10f;  // 2^-32
+    const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
+    const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
+    const float r0 = sqrtf(-2.f * __logf(fmaxf(u0, 1e-30f))), r1 = sqrtf(-2.f * __logf(fmaxf(u2, 1e-30f)));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u1, &s0, &c0);
+    __sincosf(6.283185307179586f * u3, &s1, &c1);
+    o[0] = r0 * c0; o[1] = r0 * s0; o[2] = r1 * c1; o[3] = r1 * s1;
+}
+
+struct NoiseAdd {
+    const float* x; float* y; RowView xv, yv; float sigma; uint64_t seed, offset;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float u[VEC];
+        ld<VEC>(x + offs(m, xv, p), u);
+        // logical (contiguous) element index -> counter; independent of the views' strides
+        const uint64_t row = ((uint64_t)p.n * m.C + p.c) * m.D + p.d;
+        const uint64_t e = row * ((uint64_t)m.H * m.W) + (m.inner == 1 ? (uint64_t)p.h * m.W + p.w : (uint64_t)p.col);
+        float z[4];
+        normal4(seed, offset, e >> 2, z);
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] += sigma * z[i];
+        } else {
+            u[0] += sigma * z[e & 3];
+        }
+        st<VEC>(y + offs(m, yv, p), u);
+    }
+};
+
+__global__ void normal_fill_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    float z[4];
+    normal4(seed, offset, (uint64_t)q, z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (q * 4 + i < n) out[q * 4 + i] = z[i];
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, uint64_t seed, uint64_t offset) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float keep = 1.f / (1.f - p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (q * 4 + i < n) mask[q * 4 + i] = (((float)c[i] + 0.5f) * 2.3283064365386963e-10f >= p) ? keep : 0.f;
+}
+
+// ------------------------------------------------------------------------- //
+// BatchNorm
+// ------------------------------------------------------------------------- //
+// wave64 sum via DPP-free shuffles, then LDS across the 4 waves
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wave * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = red[i] + red[NV + i] + red[2 * NV + i] + red[3 * NV + i];
+}
+
+// channel-wise iteration: groups of channel c are g = (n*D + d)*gpr + cg
+struct ChanMap {
+    int32_t N, C, D, H, W, inner, vec, gpr;
+    FastDiv div_gpr, div_d, div_w;
+    int64_t per_chan;   // groups per channel
+    int32_t split;      // blocks per channel
+    int64_t seg;        // groups per block
+};
+static ChanMap make_chanmap(const RowMap& m) {
+    ChanMap c;
+    memset(&c, 0, sizeof(c));
+    c.N = m.N; c.C = m.C; c.D = m.D; c.H = m.H; c.W = m.W; c.inner = m.inner; c.vec = m.vec; c.gpr = m.gpr;
+    c.div_gpr = m.div_gpr; c.div_d = m.div_d; c.div_w = m.div_w;
+    c.per_chan = (int64_t)m.N * m.D * m.gpr;
+    int64_t split = (2048 + m.C - 1) / m.C;           // ~2048 blocks in total
+    const int64_t maxsplit = (c.per_chan + 1023) / 1024;  // >= 4 groups per thread
+    if (split > maxsplit) split = maxsplit;
+    if (split < 1) split = 1;
+    c.split = (int)split;
+    c.seg = (c.per_chan + split - 1) / split;
+    return c;
+}
+__device__ __forceinline__ Pos locate_c(const ChanMap& m, int c, uint32_t g) {
+    Pos p;
+    const uint32_t nd = fdiv(g, m.div_gpr);
+    const uint32_t cg = g - nd * m.div_gpr.div;
+    const uint32_t n = fdiv(nd, m.div_d);
+    p.n = (int)n; p.c = c; p.d = (int)(nd - n * m.div_d.div);
+    p.col = (int)cg * m.vec;
+    if (m.inner == 1) {
+        const uint32_t h = fdiv(cg, m.div_w);
+        p.h = (int)h; p.w = (int)(cg - h * m.div_w.div);
+    } else { p.h = 0; p.w = 0; }
+    return p;
+}
+__device__ __forceinline__ int64_t offs_c(const ChanMap& m, const RowView& v, const Pos& p) {
+    int64_t o = (int64_t)p.n * v.sn + (int64_t)p.c * v.sc + (int64_t)p.d * v.sd;
+    if (m.inner == 1) o += (int64_t)p.h * v.sh + (int64_t)p.w * v.sw;
+    else o += p.col;
+    return o;
+}
+
+// partial[c][s] = {sum x, sum x^2} over the block's segment
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_stats_kernel(ChanMap m, const float* __restrict__ x, RowView xv, double* __restrict__ partial) {
+    __shared__ double red[8];
+    const int c = blockIdx.x / m.split, s = blockIdx.x % m.split;
+    const int64_t g0 = (int64_t)s * m.seg;
+    int64_t g1 = g0 + m.seg;
+    if (g1 > m.per_chan) g1 = m.per_chan;
+    float a0 = 0.f, a1 = 0.f;
+    double acc[2] = {0.0, 0.0};
+    int cnt = 0;
+    for (int64_t g = g0 + threadIdx.x; g < g1; g += 256) {
+        const Pos p = locate_c(m, c, (uint32_t)g);
+        float v[VEC];
+        ld<VEC>(x + offs_c(m, xv, p), v);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { a0 += v[i]; a1 += v[i] * v[i]; }
+        if (++cnt == 64) { acc[0] += a0; acc[1] += a1; a0 = a1 = 0.f; cnt = 0; }  // bound fp32 run length
+    }
+    acc[0] += a0; acc[1] += a1;
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { partial[(int64_t)blockIdx.x * 2] = acc[0]; partial[(int64_t)blockIdx.x * 2 + 1] = acc[1]; }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int C, int split, double count, float eps, float momentum,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < split; ++k) { s0 += partial[((int64_t)c * split + k) * 2]; s1 += partial[((int64_t)c * split + k) * 2 + 1]; }
+    const double mean = s0 / count;
+    double var = s1 / count - mean * mean;
+    if (var < 0) var = 0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1 ? var * count / (count - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_stats_kernel(int C, float eps, const float* __restrict__ rm, const float* __restrict__ rv_, float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rm[c];
+    invstd[c] = 1.f / sqrtf(rv_[c] + eps);
+}
+
+struct BnApply {
+    const float* x; float* y; RowView xv, yv;
+    const float* gamma; const float* beta; const float* mean; const float* invstd; const float* mask;
+    int act; float slope;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float v[VEC];
+        ld<VEC>(x + offs(m, xv, p), v);
+        const float sc = gamma[p.c] * invstd[p.c];
+        const float sh = beta[p.c] - mean[p.c] * sc;
+        const float mk = mask ? mask[(int64_t)p.n * m.C + p.c] : 1.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) v[i] = act_fwd((v[i] * sc + sh) * mk, act, slope);
+        st<VEC>(y + offs(m, yv, p), v);
+    }
+};
+
+// backward pass 1: partial[c][s] = {sum dz, sum dz * xhat},  dz = dy * act'(z) * mask
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(ChanMap m, const float* __restrict__ dy, RowView dyv, const float* __restrict__ x, RowView xv,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ mask,
+                                                            int act, float slope, double* __restrict__ partial) {
+    __shared__ double red[8];
+    const int c = blockIdx.x / m.split, s = blockIdx.x % m.split;
+    const int64_t g0 = (int64_t)s * m.seg;
+    int64_t g1 = g0 + m.seg;
+    if (g1 > m.per_chan) g1 = m.per_chan;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    float a0 = 0.f, a1 = 0.f;
+    double acc[2] = {0.0, 0.0};
+    int cnt = 0;
+    for (int64_t g = g0 + threadIdx.x; g < g1; g += 256) {
+        const Pos p = locate_c(m, c, (uint32_t)g);
+        float v[VEC], d[VEC];
+        ld<VEC>(x + offs_c(m, xv, p), v);
+        ld<VEC>(dy + offs_c(m, dyv, p), d);
+        const float mk = mask ? mask[(int64_t)p.n * m.C + c] : 1.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xh = (v[i] - mu) * is;
+            const float z = (ga * xh + be) * mk;
+            float dz = d[i] * mk;
+            if (act == DCV_ACT_LEAKY) dz *= (z > 0.f ? 1.f : slope);
+            else if (act == DCV_ACT_TANH) { const float t = tanhf(z); dz *= 1.f - t * t; }
+            a0 += dz; a1 += dz * xh;
+        }
+        if (++cnt == 64) { acc[0] += a0; acc[1] += a1; a0 = a1 = 0.f; cnt = 0; }
+    }
+    acc[0] += a0; acc[1] += a1;
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { partial[(int64_t)blockIdx.x * 2] = acc[0]; partial[(int64_t)blockIdx.x * 2 + 1] = acc[1]; }
+}
+
+// dbeta = sum dz, dgamma = sum dz*xhat; coef[c] = {dbeta/count, dgamma/count} for pass 2
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int C, int split, double count,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < split; ++k) { s0 += partial[((int64_t)c * split + k) * 2]; s1 += partial[((int64_t)c * split + k) * 2 + 1]; }
+    dbeta[c] = (float)s0;
+    dgamma[c] = (float)s1;
+    coef[2 * c] = (float)(s0 / count);
+    coef[2 * c + 1] = (float)(s1 / count);
+}
+
+struct BnBwdApply {
+    const float* dy; const float* x; float* dx; RowView dyv, xv, dxv;
+    const float* gamma; const float* beta; const float* mean; const float* invstd; const float* mask; const float* coef;
+    int act; float slope; int training;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float v[VEC], d[VEC];
+        ld<VEC>(x + offs(m, xv, p), v);
+        ld<VEC>(dy + offs(m, dyv, p), d);
+        const int c = p.c;
+        const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+        const float mk = mask ? mask[(int64_t)p.n * m.C + c] : 1.f;
+        const float k0 = training ? coef[2 * c] : 0.f, k1 = training ? coef[2 * c + 1] : 0.f;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float xh = (v[i] - mu) * is;
+            const float z = (ga * xh + be) * mk;
+            float dz = d[i] * mk;
+            if (act == DCV_ACT_LEAKY) dz *= (z > 0.f ? 1.f : slope);
+            else if (act == DCV_ACT_TANH) { const float t = tanhf(z); dz *= 1.f - t * t; }
+            v[i] = ga * is * (dz - k0 - xh * k1);
+        }
+        st<VEC>(dx + offs(m, dxv, p), v);
+    }
+};
+
+// ------------------------------------------------------------------------- //
+// GAN loss: one block, value + gradient
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void gan_loss_kernel(const float* __restrict__ y, int64_t n, int kind, float* __restrict__ loss_out, int accumulate, float* __restrict__ dy) {
+    __shared__ double red[4];
+    const float inv = 1.f / (float)n;
+    double acc[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float v = y[i];
+        float f, g;
+        if (kind == 0 || kind == 4) {        // softplus(-v)
+            f = fmaxf(-v, 0.f) + log1pf(expf(-fabsf(v)));
+            g = -1.f / (1.f + expf(v));
+        } else if (kind == 1) {              // softplus(v)
+            f = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
+            g = 1.f / (1.f + expf(-v));
+        } else if (kind == 2) {              // relu(1 - v)
+            f = fmaxf(1.f - v, 0.f);
+            g = (1.f - v > 0.f) ? -1.f : 0.f;
+        } else {                             // relu(1 + v)
+            f = fmaxf(1.f + v, 0.f);
+            g = (1.f + v > 0.f) ? 1.f : 0.f;
+        }
+        acc[0] += (double)f;
+        if (dy) dy[i] = g * inv;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) {
+        const float val = (float)(acc[0] / (double)n);
+        *loss_out = accumulate ? *loss_out + val : val;
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// Adam
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// GRU recurrence (dm <= 32): one 64-lane block per sample, lane u < dm owns unit u
+// ------------------------------------------------------------------------- //
+#define GRU_MAXD 32
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(64) void gru_fwd_kernel(const float* __restrict__ e, const float* __restrict__ h0, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                                     const float* __restrict__ b_ih, const float* __restrict__ b_hh, float* __restrict__ out, float* __restrict__ gates,
+                                                     int T, int B, int dm) {
+    __shared__ float h[GRU_MAXD], x[GRU_MAXD];
+    const int b = blockIdx.x, u = threadIdx.x;
+    if (u < dm) h[u] = h0[(int64_t)b * dm + u];
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        if (u < dm) x[u] = e[((int64_t)t * B + b) * dm + u];
+        __syncthreads();
+        float hn_new = 0.f;
+        if (u < dm) {
+            float ir = b_ih[u], iz = b_ih[dm + u], in_ = b_ih[2 * dm + u];
+            float hr = b_hh[u], hz = b_hh[dm + u], hn = b_hh[2 * dm + u];
+            for (int k = 0; k < dm; ++k) {
+                const float xk = x[k], hk = h[k];
+                ir += w_ih[(int64_t)u * dm + k] * xk;
+                iz += w_ih[(int64_t)(dm + u) * dm + k] * xk;
+                in_ += w_ih[(int64_t)(2 * dm + u) * dm + k] * xk;
+                hr += w_hh[(int64_t)u * dm + k] * hk;
+                hz += w_hh[(int64_t)(dm + u) * dm + k] * hk;
+                hn += w_hh[(int64_t)(2 * dm + u) * dm + k] * hk;
+            }
+            const float r = sigmoidf_(ir + hr), z = sigmoidf_(iz + hz);
+            const float n = tanhf(in_ + r * hn);
+            hn_new = n + z * (h[u] - n);
+            float* gt = gates + ((int64_t)t * B + b) * 4 * dm;
+            gt[u] = r; gt[dm + u] = z; gt[2 * dm + u] = n; gt[3 * dm + u] = hn;
+            out[((int64_t)b * T + t) * dm + u] = hn_new;
+        }
+        __syncthreads();
+        if (u < dm) h[u] = hn_new;
+        __syncthreads();
+    }
+}
+
+// per-sample BPTT; partial parameter gradients go to part[b][P], P = 6*dm*dm + 6*dm,
+// layout [dw_ih (3dm*dm) | dw_hh (3dm*dm) | db_ih (3dm) | db_hh (3dm)]
+__global__ __launch_bounds__(64) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ e, const float* __restrict__ h0, const float* __restrict__ out,
+                                                     const float* __restrict__ gates, const float* __restrict__ w_hh, float* __restrict__ part, int T, int B, int dm) {
+    __shared__ float dgh[3 * GRU_MAXD], dh[GRU_MAXD];
+    const int b = blockIdx.x, u = threadIdx.x;
+    const int P = 6 * dm * dm + 6 * dm;
+    float* pp = part + (int64_t)b * P;
+    for (int i = u; i < P; i += 64) pp[i] = 0.f;
+    if (u < dm) dh[u] = 0.f;
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dhn = 0.f, dh_keep = 0.f;
+        if (u < dm) {
+            const float* gt = gates + ((int64_t)t * B + b) * 4 * dm;
+            const float r = gt[u], z = gt[dm + u], n = gt[2 * dm + u], hn = gt[3 * dm + u];
+            const float hprev = t > 0 ? out[((int64_t)b * T + t - 1) * dm + u] : h0[(int64_t)b * dm + u];
+            const float d = dout[((int64_t)b * T + t) * dm + u] + dh[u];
+            const float dn = d * (1.f - z);
+            const float dz = d * (hprev - n);
+            dh_keep = d * z;
+            dn_pre = dn * (1.f - n * n);
+            dhn = dn_pre * r;
+            dr_pre = dn_pre * hn * r * (1.f - r);
+            dz_pre = dz * z * (1.f - z);
+            dgh[u] = dr_pre; dgh[dm + u] = dz_pre; dgh[2 * dm + u] = dhn;
+            // parameter gradients owned by this lane: rows u, dm+u, 2dm+u
+            for (int k = 0; k < dm; ++k) {
+                const float xk = e[((int64_t)t * B + b) * dm + k];
+                const float hk = t > 0 ? out[((int64_t)b * T + t - 1) * dm + k] : h0[(int64_t)b * dm + k];
+                pp[(int64_t)u * dm + k] += dr_pre * xk;
+                pp[(int64_t)(dm + u) * dm + k] += dz_pre * xk;
+                pp[(int64_t)(2 * dm + u) * dm + k] += dn_pre * xk;
+                pp[3 * dm * dm + (int64_t)u * dm + k] += dr_pre * hk;
+                pp[3 * dm * dm + (int64_t)(dm + u) * dm + k] += dz_pre * hk;
+                pp[3 * dm * dm + (int64_t)(2 * dm + u) * dm + k] += dhn * hk;
+            }
+            float* pb = pp + 6 * dm * dm;
+            pb[u] += dr_pre; pb[dm + u] += dz_pre; pb[2 * dm + u] += dn_pre;
+            pb[3 * dm + u] += dr_pre; pb[4 * dm + u] += dz_pre; pb[5 * dm + u] += dhn;
+        }
+        __syncthreads();
+        if (u < dm) {
+            float s = dh_keep;
+            for (int j = 0; j < 3 * dm; ++j) s += w_hh[(int64_t)j * dm + u] * dgh[j];
+            dh[u] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void gru_reduce_kernel(const float* __restrict__ part, int B, int P, int dm, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[(int64_t)b * P + i];
+    const int w = 3 * dm * dm;
+    if (i < w) dw_ih[i] = s;
+    else if (i < 2 * w) dw_hh[i - w] = s;
+    else if (i < 2 * w + 3 * dm) db_ih[i - 2 * w] = s;
+    else db_hh[i - 2 * w - 3 * dm] = s;
+}
+
+}  // namespace dcv
+
+using namespace dcv;
+
+extern "C" {
+
+size_t dcv_bn_workspace_bytes(int channels) {
+    // partial sums: C * split * 2 doubles (split <= 2048) + coef (2C floats)
+    return (size_t)(2048 + channels) * 2 * sizeof(double) * 2 + (size_t)channels * 2 * sizeof(float) + 512;
+}
+
+int dcv_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, int act, float slope, void* stream) {
+    if (!x || !y || !xd || !yd || !same_shape(*xd, *yd)) return fail(DCV_EINVAL, "act_forward: bad arguments");
+    const dcv_dims5* views[2] = {xd, yd};
+    const void* ptrs[2] = {x, y};
+    RowMap m = make_rowmap(*xd, views, 2, ptrs);
+    ActFwd f{x, y, rv(*xd), rv(*yd), act, slope};
+    return launch_ew(m, f, static_cast<hipStream_t>(stream));
+}
+
+int dcv_act_backward(const float* dy, const dcv_dims5* dyd, const float* y, const dcv_dims5* yd, float* dx, const dcv_dims5* dxd, int act, float slope, void* stream) {
+    if (!dy || !y || !dx || !same_shape(*dyd, *yd) || !same_shape(*dyd, *dxd)) return fail(DCV_EINVAL, "act_backward: bad arguments");
+    const dcv_dims5* views[3] = {dyd, yd, dxd};
+    const void* ptrs[3] = {dy, y, dx};
+    RowMap m = make_rowmap(*dyd, views, 3, ptrs);
+    ActBwd f{dy, y, dx, rv(*dyd), rv(*yd), rv(*dxd), act, slope};
+    return launch_ew(m, f, static_cast<hipStream_t>(stream));
+}
+
+int dcv_axpby(const float* x, const dcv_dims5* xd, float a, const float* z, const dcv_dims5* zd, float b, float* y, const dcv_dims5* yd, void* stream) {
+    if (!x || !y || !xd || !yd || !same_shape(*xd, *yd) || (z && (!zd || !same_shape(*xd, *zd)))) return fail(DCV_EINVAL, "axpby: bad arguments");
+    const dcv_dims5* views[3] = {xd, yd, z ? zd : xd};
+    const void* ptrs[3] = {x, y, z ? z : x};
+    RowMap m = make_rowmap(*xd, views, 3, ptrs);
+    Axpby f{x, z, y, rv(*xd), z ? rv(*zd) : rv(*xd), rv(*yd), a, b};
+    return launch_ew(m, f, static_cast<hipStream_t>(stream));
+}
+
+int dcv_noise_add(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, float sigma, uint64_t seed, uint64_t offset, void* stream) {
+    if (!x || !y || !same_shape(*xd, *yd)) return fail(DCV_EINVAL, "noise_add: bad arguments");
+    const dcv_dims5* views[2] = {xd, yd};
+    const void* ptrs[2] = {x, y};
+    RowMap m = make_rowmap(*xd, views, 2, ptrs);
+    NoiseAdd f{x, y, rv(*xd), rv(*yd), sigma, seed, offset};
+    return launch_ew(m, f, static_cast<hipStream_t>(stream));
+}
+
+int dcv_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n < 0) return fail(DCV_EINVAL, "normal_fill: bad arguments");
+    if (n == 0) return DCV_OK;
+    const int64_t q = (n + 3) / 4;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, seed, offset);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!mask || n < 0 || p < 0.f || p >= 1.f) return fail(DCV_EINVAL, "dropout_mask: bad arguments");
+    if (n == 0) return DCV_OK;
+    const int64_t q = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), mask, n, p, seed, offset);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* mask,
+                       int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !same_shape(*xd, *yd)) return fail(DCV_EINVAL, "bn_act_forward: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = xd->c;
+    const dcv_dims5* views[2] = {xd, yd};
+    const void* ptrs[2] = {x, y};
+    RowMap m = make_rowmap(*xd, views, 2, ptrs);
+    if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
+    if (training) {
+        if (ws_bytes < dcv_bn_workspace_bytes(C) || !ws) return fail(DCV_EWORKSPACE, "bn_act_forward: workspace too small");
+        ChanMap cm = make_chanmap(m);
+        double* partial = static_cast<double*>(ws);
+        if (m.vec == 4) hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(C * cm.split), dim3(256), 0, s, cm, x, rv(*xd), partial);
+        else hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(C * cm.split), dim3(256), 0, s, cm, x, rv(*xd), partial);
+        DCV_LAUNCH_CHECK();
+        const double count = (double)xd->n * xd->d * xd->h * xd->w;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, cm.split, count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+        DCV_LAUNCH_CHECK();
+    } else {
+        if (!running_mean || !running_var) return fail(DCV_EINVAL, "bn_act_forward: eval mode needs running stats");
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, eps, running_mean, running_var, save_mean, save_invstd);
+        DCV_LAUNCH_CHECK();
+    }
+    BnApply f{x, y, rv(*xd), rv(*yd), gamma, beta, save_mean, save_invstd, mask, act, slope};
+    return launch_ew(m, f, s);
+}
+
+int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, const dcv_dims5* xd, float* dx, const dcv_dims5* dxd,
+                        const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const float* mask,
+                        int training, int act, float slope, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !dx || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !same_shape(*dyd, *xd) || !same_shape(*dyd, *dxd))
+        return fail(DCV_EINVAL, "bn_act_backward: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = xd->c;
+    if (ws_bytes < dcv_bn_workspace_bytes(C) || !ws) return fail(DCV_EWORKSPACE, "bn_act_backward: workspace too small");
+    const dcv_dims5* views[3] = {dyd, xd, dxd};
+    const void* ptrs[3] = {dy, x, dx};
+    RowMap m = make_rowmap(*xd, views, 3, ptrs);
+    if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
+    ChanMap cm = make_chanmap(m);
+    double* partial = static_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)(2048 + C) * 2 * sizeof(double) * 2);
+    if (m.vec == 4)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<4>), dim3(C * cm.split), dim3(256), 0, s, cm, dy, rv(*dyd), x, rv(*xd), gamma, beta, save_mean, save_invstd, mask, act, slope, partial);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<1>), dim3(C * cm.split), dim3(256), 0, s, cm, dy, rv(*dyd), x, rv(*xd), gamma, beta, save_mean, save_invstd, mask, act, slope, partial);
+    DCV_LAUNCH_CHECK();
+    const double count = (double)xd->n * xd->d * xd->h * xd->w;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, cm.split, count, dgamma, dbeta, coef);
+    DCV_LAUNCH_CHECK();
+    BnBwdApply f{dy, x, dx, rv(*dyd), rv(*xd), rv(*dxd), gamma, beta, save_mean, save_invstd, mask, coef, act, slope, training};
+    return launch_ew(m, f, s);
+}
+
+int dcv_gan_loss(const float* y, int64_t n, int kind, float* loss_out, int accumulate, float* dy_out, void* stream) {
+    if (!y || !loss_out || n < 1 || kind < 0 || kind > 4) return fail(DCV_EINVAL, "gan_loss: bad arguments");
+    hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), y, n, kind, loss_out, accumulate, dy_out);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n < 0 || step < 1) return fail(DCV_EINVAL, "adam_step: bad arguments");
+    if (n == 0) return DCV_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+size_t dcv_gru_workspace_bytes(int B, int dm) { return (size_t)B * (6 * dm * dm + 6 * dm) * sizeof(float) + 256; }
+
+int dcv_gru_forward(const float* e, const float* h0, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                    float* out, float* gates, int T, int B, int dm, void* stream) {
+    if (!e || !h0 || !w_ih || !w_hh || !b_ih || !b_hh || !out || !gates || T < 1 || B < 1 || dm < 1 || dm > GRU_MAXD) return fail(DCV_EINVAL, "gru_forward: bad arguments");
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), e, h0, w_ih, w_hh, b_ih, b_hh, out, gates, T, B, dm);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_gru_backward(const float* dout, const float* e, const float* h0, const float* out, const float* gates, const float* w_ih, const float* w_hh,
+                     float* dw_ih, float* dw_hh, float* db_ih, float* db_hh, int T, int B, int dm, void* ws, size_t ws_bytes, void* stream) {
+    (void)w_ih;
+    if (!dout || !e || !h0 || !out || !gates || !w_hh || !dw_ih || !dw_hh || !db_ih || !db_hh || dm > GRU_MAXD) return fail(DCV_EINVAL, "gru_backward: bad arguments");
+    if (!ws || ws_bytes < dcv_gru_workspace_bytes(B, dm)) return fail(DCV_EWORKSPACE, "gru_backward: workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(64), 0, s, dout, e, h0, out, gates, w_hh, part, T, B, dm);
+    DCV_LAUNCH_CHECK();
+    const int P = 6 * dm * dm + 6 * dm;
+    hipLaunchKernelGGL(gru_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, s, part, B, P, dm, dw_ih, dw_hh, db_ih, db_hh);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""ctypes binding of libdcvgan_hip.so (include/dcvgan_hip.h).
+
+There is NO fallback: if the library is missing, or a call fails, a
+``NativeError`` is raised.  PyTorch is used for device memory and streams only;
+every pointer handed over is ``tensor.data_ptr()`` and the stream is the current
+HIP stream of the calling thread (autograd's backward thread included).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcvgan_hip.so")
+
+ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Dims5(C.Structure):
+    _fields_ = [("n", C.c_int32), ("c", C.c_int32), ("d", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("sn", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+                ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
+                ("transposed", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32)]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+_P = C.c_void_p
+_D = C.POINTER(Dims5)
+_G = C.POINTER(ConvGeom)
+_SIGS = {
+    "dcv_last_error": (C.c_char_p, []),
+    "dcv_version": (C.c_int, []),
+    "dcv_launch_count": (C.c_uint64, []),
+    "dcv_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
+    "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
+    "dcv_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "dcv_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_bn_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_size_t, _P]),
+    "dcv_act_forward": (C.c_int, [_P, _D, _P, _D, C.c_int, C.c_float, _P]),
+    "dcv_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, C.c_int, C.c_float, _P]),
+    "dcv_axpby": (C.c_int, [_P, _D, C.c_float, _P, _D, C.c_float, _P, _D, _P]),
+    "dcv_noise_add": (C.c_int, [_P, _D, _P, _D, C.c_float, C.c_uint64, C.c_uint64, _P]),
+    "dcv_normal_fill": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "dcv_dropout_mask": (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, _P]),
+    "dcv_gan_loss": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, _P]),
+    "dcv_gru_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "dcv_gru_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "dcv_gru_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NativeError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or dcvgan_amd/csrc/build.sh). There is no CPU/PyTorch fallback for the HIP path.")
+                l = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGS.items():
+                    fn = getattr(l, name)  # AttributeError here = header/library mismatch
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise NativeError(f"{what} failed (code {rc}): {lib().dcv_last_error().decode(errors='replace')}")
+
+
+def launch_count() -> int:
+    return int(lib().dcv_launch_count())
+
+
+# --------------------------------------------------------------------------- #
+# tensor plumbing
+# --------------------------------------------------------------------------- #
+def _require(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise NativeError(f"{what}: expected a HIP device tensor, got {t.device} — the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise NativeError(f"{what}: expected float32, got {t.dtype}")
+
+
+def dims5(t: torch.Tensor) -> Dims5:
+    """Describe a 2-D (N,C), 4-D (N,C,H,W) or 5-D (N,C,D,H,W) tensor view."""
+    sz, st = list(t.shape), list(t.stride())
+    if t.dim() == 2:
+        sz, st = sz + [1, 1, 1], st + [0, 0, 0]
+    elif t.dim() == 4:
+        sz, st = sz[:2] + [1] + sz[2:], st[:2] + [0] + st[2:]
+    elif t.dim() != 5:
+        raise NativeError(f"unsupported tensor rank {t.dim()}")
+    # size-1 dims may carry arbitrary strides; normalise them for the kernels' contiguity tests
+    for i in range(5):
+        if sz[i] == 1:
+            st[i] = 0
+    return Dims5(*sz, *st)
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Scratch(threading.local):
+    """Per-thread, per-device grow-only scratch buffers (workspace the C ABI asks
+    the caller to own).  Stream-ordered reuse is safe: all launches that touch a
+    buffer are on the calling thread's current stream."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, tag: str, nbytes: int, device) -> torch.Tensor:
+        key = (tag, str(device), torch.cuda.current_stream(device).cuda_stream)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+scratch = _Scratch()

@@ -1,0 +1,341 @@
+"""Autograd tape entries whose forward/backward launch the gfx950 kernels.
+
+PyTorch supplies the tape, device memory and the current stream; every tensor
+computation of the G+D step below goes through libdcvgan_hip.so (native.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import native as N
+from .native import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvGeom, check, dims5, lib, ptr, stream_ptr
+
+__all__ = ["conv", "bn_act", "act", "noise_add", "cat_channels", "temporal_diff", "gan_loss", "gru_sequence",
+           "normal", "dropout2d_mask", "conv_geom", "ACT_NONE", "ACT_LEAKY", "ACT_TANH"]
+
+
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    """Gradients can arrive as expanded (stride-0) views; give the kernels real memory."""
+    if any(s == 0 and n > 1 for s, n in zip(t.stride(), t.shape)):
+        return t.contiguous()
+    return t
+
+
+def _ws(tag: str, nbytes: int, device) -> Tuple[C.c_void_p, int]:
+    buf = N.scratch.get(tag, int(nbytes), device)
+    return C.c_void_p(buf.data_ptr()), buf.numel()
+
+
+# --------------------------------------------------------------------------- #
+# convolution
+# --------------------------------------------------------------------------- #
+def conv_geom(weight: torch.Tensor, stride, padding, transposed: bool) -> ConvGeom:
+    """Geometry from a torch weight: (Cout,Cin,k..) or, transposed, (Cin,Cout,k..)."""
+    k = list(weight.shape[2:])
+    s, p = list(stride), list(padding)
+    if len(k) == 2:
+        k, s, p = [1] + k, [1] + s, [0] + p
+    a, b = weight.shape[0], weight.shape[1]
+    cin, cout = (a, b) if transposed else (b, a)
+    return ConvGeom(k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], int(transposed), cin, cout)
+
+
+def _out_shape(g: ConvGeom, x: torch.Tensor):
+    sp = list(x.shape[2:])
+    if len(sp) == 2:
+        sp = [1] + sp
+    ks, ss, ps = (g.kd, g.kh, g.kw), (g.sd, g.sh, g.sw), (g.pd, g.ph, g.pw)
+    if g.transposed:
+        o = [(sp[i] - 1) * ss[i] - 2 * ps[i] + ks[i] for i in range(3)]
+    else:
+        o = [(sp[i] + 2 * ps[i] - ks[i]) // ss[i] + 1 for i in range(3)]
+    if x.dim() == 4:
+        return (x.shape[0], g.cout, o[1], o[2])
+    return (x.shape[0], g.cout, o[0], o[1], o[2])
+
+
+class _Conv(Function):
+    @staticmethod
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float):
+        N._require(x, "conv input"); N._require(w, "conv weight")
+        if x.shape[1] != g.cin:
+            raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
+        w = w.contiguous()
+        y = torch.empty(_out_shape(g, x), dtype=torch.float32, device=x.device)
+        xd, yd = dims5(x), dims5(y)
+        L = lib()
+        need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0)
+        if need == 0:
+            raise N.NativeError("conv forward: " + L.dcv_last_error().decode())
+        wsp, wsn = _ws("conv", need, x.device)
+        check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_conv_forward")
+        ctx.g, ctx.act, ctx.slope = g, act, slope
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        g = ctx.g
+        L = lib()
+        dy = _dense(dy)
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(y)
+            dyd, yd = dims5(dy), dims5(y)
+            check(L.dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dz), C.byref(yd), ctx.act, ctx.slope, stream_ptr()), "dcv_act_backward")
+            dy = dz
+        xd, dyd = dims5(x), dims5(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            dxd = dims5(dx)
+            need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1)
+            wsp, wsn = _ws("conv", need, x.device)
+            check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), 0, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
+            wsp, wsn = _ws("conv", need, x.device)
+            check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
+        return dx, dw, None, None, None
+
+
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0):
+    """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries."""
+    return _Conv.apply(x, w, g, act, float(slope))
+
+
+# --------------------------------------------------------------------------- #
+# BatchNorm (+ Dropout2d mask) + activation
+# --------------------------------------------------------------------------- #
+class _BnAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float):
+        N._require(x, "bn input")
+        L = lib()
+        Cn = x.shape[1]
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        stats = torch.empty(2, Cn, dtype=torch.float32, device=x.device)
+        xd, yd = dims5(x), dims5(y)
+        wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
+        check(L.dcv_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                   ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope, wsp, wsn, stream_ptr()),
+              "dcv_bn_act_forward")
+        ctx.cfg = (bool(training), act, slope)
+        ctx.save_for_backward(x, gamma, beta, stats, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats, mask = ctx.saved_tensors
+        training, act, slope = ctx.cfg
+        L = lib()
+        dy = _dense(dy)
+        Cn = x.shape[1]
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        dgb = torch.empty(2, Cn, dtype=torch.float32, device=x.device)
+        dyd, xd, dxd = dims5(dy), dims5(x), dims5(dx)
+        wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
+        check(L.dcv_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta),
+                                    ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()),
+              "dcv_bn_act_backward")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0,
+           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5):
+    """y = act(mask * batch_norm(x)); running stats are updated in place when training."""
+    return _BnAct.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope))
+
+
+# --------------------------------------------------------------------------- #
+# activation
+# --------------------------------------------------------------------------- #
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act: int, slope: float):
+        N._require(x, "activation input")
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        xd, yd = dims5(x), dims5(y)
+        check(lib().dcv_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), act, slope, stream_ptr()), "dcv_act_forward")
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        dy = _dense(dy)
+        dx = torch.empty_like(y)
+        dyd, yd = dims5(dy), dims5(y)
+        check(lib().dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dx), C.byref(yd), act, slope, stream_ptr()), "dcv_act_backward")
+        return dx, None, None
+
+
+def act(x, kind: int, slope: float = 0.0):
+    return _Act.apply(x, kind, float(slope))
+
+
+# --------------------------------------------------------------------------- #
+# axpby-based pieces: noise add, channel concat, temporal difference
+# --------------------------------------------------------------------------- #
+def _axpby(x, a, z, b, out):
+    xd, od = dims5(x), dims5(out)
+    zd = dims5(z) if z is not None else None
+    check(lib().dcv_axpby(ptr(x), C.byref(xd), float(a), ptr(z), C.byref(zd) if z is not None else None, float(b), ptr(out), C.byref(od), stream_ptr()), "dcv_axpby")
+    return out
+
+
+class _NoiseAdd(Function):
+    @staticmethod
+    def forward(ctx, x, sigma: float, sample, seed: int, offset: int):
+        N._require(x, "noise input")
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        if sample is not None:  # injected draw (parity tests)
+            _axpby(x, 1.0, sample, sigma, y)
+        else:
+            xd, yd = dims5(x), dims5(y)
+            check(lib().dcv_noise_add(ptr(x), C.byref(xd), ptr(y), C.byref(yd), sigma, seed, offset, stream_ptr()), "dcv_noise_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None, None
+
+
+def noise_add(x, sigma: float, sample=None, seed: int = 0, offset: int = 0):
+    """x + sigma * N(0,1): device Philox draw, or an injected `sample` tensor."""
+    return _NoiseAdd.apply(x, float(sigma), sample, int(seed), int(offset))
+
+
+class _CatChannels(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        N._require(a, "cat input"); N._require(b, "cat input")
+        ca, cb = a.shape[1], b.shape[1]
+        out = torch.empty((a.shape[0], ca + cb) + tuple(a.shape[2:]), dtype=torch.float32, device=a.device)
+        _axpby(a, 1.0, None, 0.0, out[:, :ca])
+        _axpby(b, 1.0, None, 0.0, out[:, ca:])
+        ctx.ca = ca
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[:, :ctx.ca], dy[:, ctx.ca:]
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], 1) as two strided copies into channel slices."""
+    return _CatChannels.apply(a, b)
+
+
+class _TemporalDiff(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N._require(x, "temporal_diff input")
+        L = x.shape[2]
+        y = torch.empty((x.shape[0], x.shape[1], L - 1) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        _axpby(x[:, :, 1:L], 1.0, x[:, :, 0:L - 1], -1.0, y)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        L = ctx.shape[2]
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        _axpby(dy[:, :, 0:1], -1.0, None, 0.0, dx[:, :, 0:1])
+        _axpby(dy[:, :, L - 2:L - 1], 1.0, None, 0.0, dx[:, :, L - 1:L])
+        if L > 2:
+            _axpby(dy[:, :, 0:L - 2], 1.0, dy[:, :, 1:L - 1], -1.0, dx[:, :, 1:L - 1])
+        return dx
+
+
+def temporal_diff(x):
+    """x[:, :, 1:] - x[:, :, :-1]  (discriminator.py:330-331)."""
+    return _TemporalDiff.apply(x)
+
+
+# --------------------------------------------------------------------------- #
+# GAN losses
+# --------------------------------------------------------------------------- #
+KIND_BCE_ONES, KIND_BCE_ZEROS, KIND_HINGE_REAL, KIND_HINGE_FAKE, KIND_SOFTPLUS_NEG = range(5)
+
+
+class _GanLoss(Function):
+    @staticmethod
+    def forward(ctx, y, kind: int):
+        N._require(y, "loss input")
+        yc = y.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=y.device)
+        dy = torch.empty_like(yc)
+        check(lib().dcv_gan_loss(ptr(yc), yc.numel(), kind, ptr(out), 0, ptr(dy), stream_ptr()), "dcv_gan_loss")
+        ctx.save_for_backward(dy)
+        ctx.shape = tuple(y.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dy,) = ctx.saved_tensors
+        return (dy * g).view(ctx.shape), None
+
+
+def gan_loss(y, kind: int):
+    return _GanLoss.apply(y, kind)
+
+
+# --------------------------------------------------------------------------- #
+# GRU recurrence
+# --------------------------------------------------------------------------- #
+class _GruSeq(Function):
+    @staticmethod
+    def forward(ctx, e, h0, w_ih, w_hh, b_ih, b_hh):
+        for t in (e, h0, w_ih, w_hh, b_ih, b_hh):
+            N._require(t, "gru operand")
+        T, B, dm = e.shape
+        e, h0 = e.contiguous(), h0.contiguous()
+        w_ih, w_hh, b_ih, b_hh = w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()
+        out = torch.empty(B, T, dm, dtype=torch.float32, device=e.device)
+        gates = torch.empty(T, B, 4 * dm, dtype=torch.float32, device=e.device)
+        check(lib().dcv_gru_forward(ptr(e), ptr(h0), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(out), ptr(gates), T, B, dm, stream_ptr()), "dcv_gru_forward")
+        ctx.save_for_backward(e, h0, out, gates, w_ih, w_hh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        e, h0, out, gates, w_ih, w_hh = ctx.saved_tensors
+        T, B, dm = e.shape
+        dout = dout.contiguous()
+        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        db_ih = torch.empty(3 * dm, dtype=torch.float32, device=e.device)
+        db_hh = torch.empty(3 * dm, dtype=torch.float32, device=e.device)
+        L = lib()
+        wsp, wsn = _ws("gru", L.dcv_gru_workspace_bytes(B, dm), e.device)
+        check(L.dcv_gru_backward(ptr(dout), ptr(e), ptr(h0), ptr(out), ptr(gates), ptr(w_ih), ptr(w_hh), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh),
+                                 T, B, dm, wsp, wsn, stream_ptr()), "dcv_gru_backward")
+        return None, None, dw_ih, dw_hh, db_ih, db_hh
+
+
+def gru_sequence(e, h0, w_ih, w_hh, b_ih, b_hh):
+    """(T,B,dm) inputs, (B,dm) initial state -> (B,T,dm) hidden states (nn.GRUCell unrolled)."""
+    return _GruSeq.apply(e, h0, w_ih, w_hh, b_ih, b_hh)
+
+
+# --------------------------------------------------------------------------- #
+# random draws on the device
+# --------------------------------------------------------------------------- #
+def normal(shape, device, seed: int, offset: int) -> torch.Tensor:
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    check(lib().dcv_normal_fill(ptr(out), out.numel(), int(seed), int(offset), stream_ptr()), "dcv_normal_fill")
+    return out
+
+
+def dropout2d_mask(n: int, c: int, p: float, device, seed: int, offset: int) -> torch.Tensor:
+    out = torch.empty(n, c, 1, 1, dtype=torch.float32, device=device)
+    check(lib().dcv_dropout_mask(ptr(out), out.numel(), float(p), int(seed), int(offset), stream_ptr()), "dcv_dropout_mask")
+    return out

@@ -1,0 +1,161 @@
+/*
+ * dcvgan_hip.h — C ABI of libdcvgan_hip.so: the hand-written gfx950 (MI355X)
+ * kernels under the DCVGAN generator/discriminator training step.
+ *
+ * The reference (raahii/dcvgan) is pure Python over torch.nn; it has no FFI of
+ * its own.  Each entry point below replaces one torch.nn / torch.optim call
+ * site of the reference's hot path (file:line given per function); the Python
+ * host side (dcvgan_amd/native.py) binds them with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     the name ends in _host; all tensors are fp32;
+ *   - tensors are described as 5-D N,C,D,H,W sizes + element strides
+ *     (2-D layers use D = 1), so the non-contiguous NCDHW views the reference
+ *     produces (generator.py:139,433) are consumed without a copy;
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises the host;
+ *   - the caller owns every buffer, including `ws` scratch (size from the
+ *     matching *_workspace_bytes call; 256-byte aligned);
+ *   - return value: 0 on success, a negative DCV_E* code otherwise; nothing
+ *     throws across the ABI.  dcv_last_error() gives a text for the last
+ *     failure on the calling thread.
+ *   - re-entrant: autograd runs backward kernels from its own thread.
+ */
+#ifndef DCVGAN_HIP_H
+#define DCVGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCV_OK 0
+#define DCV_EINVAL (-1)   /* bad shape / geometry / null pointer          */
+#define DCV_EWORKSPACE (-2) /* ws too small                                */
+#define DCV_EHIP (-3)     /* a HIP runtime call failed                     */
+#define DCV_EUNSUPPORTED (-4)
+
+/* activation codes for fused epilogues / elementwise kernels */
+#define DCV_ACT_NONE 0
+#define DCV_ACT_LEAKY 1   /* LeakyReLU(slope); slope 0 = ReLU              */
+#define DCV_ACT_TANH 2
+
+typedef struct dcv_dims5 {
+    int32_t n, c, d, h, w;        /* sizes                                  */
+    int64_t sn, sc, sd, sh, sw;   /* element strides                        */
+} dcv_dims5;
+
+/* Geometry of one nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d module.
+ * cin/cout are the MODULE's in/out channels; weight layout is torch's:
+ * (cout, cin, kd, kh, kw) for conv, (cin, cout, kd, kh, kw) for transposed. */
+typedef struct dcv_conv_geom {
+    int32_t kd, kh, kw;
+    int32_t sd, sh, sw;
+    int32_t pd, ph, pw;
+    int32_t transposed;
+    int32_t cin, cout;
+} dcv_conv_geom;
+
+const char* dcv_last_error(void);
+int dcv_version(void);
+/* number of kernel launches issued through this library so far (tests use it to
+ * prove the HIP path, not a fallback, did the work) */
+uint64_t dcv_launch_count(void);
+
+/* ---- convolutions ------------------------------------------------------- *
+ * Replace nn.Conv2d (generator.py:174,204; discriminator.py:83,89,95-101),
+ * nn.Conv3d (discriminator.py:181-206,288-305) and nn.ConvTranspose2d
+ * (generator.py:61-73,239-241,273-275) forward and their autograd backward.
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32.
+ *   forward        : y = act(conv(x, w))            (act fused in the epilogue)
+ *   backward_data  : dx (+)= conv^T(dy, w)
+ *   backward_weight: dw  = corr(x, dy)              (deterministic split-K)
+ */
+size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which /*0 fwd,1 bwd-data,2 bwd-weight*/);
+int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w,
+                     float* y, const dcv_dims5* yd, int act, float slope,
+                     void* ws, size_t ws_bytes, void* stream);
+int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w,
+                           float* dx, const dcv_dims5* dxd, int accumulate,
+                           void* ws, size_t ws_bytes, void* stream);
+int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd,
+                             const float* dy, const dcv_dims5* dyd, float* dw,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNorm{2,3}d (+ Dropout2d) (+ activation) ------------------------ *
+ * Replace nn.BatchNorm2d/3d + nn.Dropout2d + nn.(Leaky)ReLU chains
+ * (generator.py:62-72,205-211,242-248; discriminator.py:96-100,191-202,290-302).
+ * Training mode: batch statistics over (N, D, H, W), biased variance for the
+ * normalisation, unbiased for running_var, momentum 0.1 (torch defaults).
+ *   y = act( mask[n,c] * ( gamma * (x - mean) * invstd + beta ) )
+ * `mask` (N*C floats, 0 or 1/(1-p)) may be NULL (no dropout).
+ * save_mean / save_invstd (C floats each) are outputs in training mode and
+ * inputs to the backward.  In eval mode (training = 0) running stats are used.
+ */
+size_t dcv_bn_workspace_bytes(int channels);
+int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd,
+                       const float* gamma, const float* beta,
+                       float* running_mean, float* running_var,
+                       float* save_mean, float* save_invstd,
+                       const float* mask, int training, float momentum, float eps,
+                       int act, float slope, void* ws, size_t ws_bytes, void* stream);
+/* dx, dgamma, dbeta from dy; x is the BN input, y unused. dgamma/dbeta are
+ * OVERWRITTEN (C floats each). */
+int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, const dcv_dims5* xd,
+                        float* dx, const dcv_dims5* dxd,
+                        const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                        const float* mask, int training, int act, float slope,
+                        float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- elementwise --------------------------------------------------------- */
+/* y = act(x)  /  dx = dy * act'(.) evaluated from the OUTPUT y
+ * (nn.LeakyReLU generator.py:175, discriminator.py:84,90,186; nn.Tanh generator.py:78,276) */
+int dcv_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, int act, float slope, void* stream);
+int dcv_act_backward(const float* dy, const dcv_dims5* dyd, const float* y, const dcv_dims5* yd,
+                     float* dx, const dcv_dims5* dxd, int act, float slope, void* stream);
+/* y = a*x + b*z   (z may be NULL): Noise add with an injected sample
+ * (discriminator.py:30-39), temporal difference of gdis (discriminator.py:330-331),
+ * gradient accumulation, strided copies (torch.cat at generator.py:393-400,
+ * discriminator.py:124,228 is two such copies into channel slices). */
+int dcv_axpby(const float* x, const dcv_dims5* xd, float a, const float* z, const dcv_dims5* zd, float b,
+              float* y, const dcv_dims5* yd, void* stream);
+/* y = x + sigma * N(0,1) drawn on the device (Philox4x32-10 + Box-Muller), the
+ * production form of discriminator.py:30-39.  (seed, offset) select the stream. */
+int dcv_noise_add(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd,
+                  float sigma, uint64_t seed, uint64_t offset, void* stream);
+/* out[i] = N(0,1), i < n   (latents: generator.py:85,88,104,356) */
+int dcv_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* Dropout2d(p) plane mask: mask[i] = Bernoulli(1-p) / (1-p), i < n = N*C (generator.py:211,248) */
+int dcv_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- GAN losses (fused value + gradient) --------------------------------- *
+ * loss.py:91-99,123-131 (BCE-with-logits, sum / numel) and loss.py:163-164,
+ * 190-191 (hinge / softplus).  kind: 0 = BCE target 1, 1 = BCE target 0,
+ * 2 = mean(relu(1 - y)), 3 = mean(relu(1 + y)), 4 = mean(softplus(-y)).
+ * *loss_out (+)= value ; dy_out[i] = d value / d y[i].                        */
+int dcv_gan_loss(const float* y, int64_t n, int kind, float* loss_out, int accumulate, float* dy_out, void* stream);
+
+/* ---- GRUCell (generator.py:58,94) --------------------------------------- *
+ * The whole T-step motion-latent recurrence in one launch: h_t = GRU(e_t, h_{t-1}).
+ * e: (T, B, dm) noise, h0: (B, dm); out: (B, T, dm) (= torch.stack(h[1:], 1));
+ * gates: (T, B, 4*dm) saved [r, z, n, hn_pre] for the backward.                */
+size_t dcv_gru_workspace_bytes(int B, int dm);
+int dcv_gru_forward(const float* e, const float* h0, const float* w_ih, const float* w_hh,
+                    const float* b_ih, const float* b_hh, float* out, float* gates,
+                    int T, int B, int dm, void* stream);
+int dcv_gru_backward(const float* dout, const float* e, const float* h0, const float* out, const float* gates,
+                     const float* w_ih, const float* w_hh,
+                     float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                     int T, int B, int dm, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Adam (train.py:171-176: betas (0.5, 0.999), eps 1e-8, L2 weight decay) */
+int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCVGAN_HIP_H */

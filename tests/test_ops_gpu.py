@@ -1,0 +1,196 @@
+"""GPU: every HIP op against the plain PyTorch fp32 CPU op it replaces (the arithmetic
+the reference delegates to torch.nn).  Tolerance: 1e-3 relative (BASELINE.json
+north_star), in practice ~1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dcvgan_amd import native
+    native.lib()
+    return torch.device("cuda:0")
+
+
+# (name, transposed, dims, Cin, Cout, k, s, p, input spatial, N)
+CONVS = [
+    ("conv2d_4s2p1", False, 2, 5, 7, 4, 2, 1, (16, 16), 3),
+    ("conv2d_4s2p1_wide", False, 2, 40, 72, 4, 2, 1, (8, 8), 5),
+    ("conv2d_4s2p1_to1x1", False, 2, 12, 9, 4, 2, 1, (2, 2), 6),
+    ("conv2d_3s1p1", False, 2, 2, 6, 3, 1, 1, (12, 12), 2),
+    ("conv2d_head", False, 2, 24, 1, 4, 2, 1, (8, 8), 4),
+    ("convT2d_4s2p1", True, 2, 6, 5, 4, 2, 1, (8, 8), 3),
+    ("convT2d_4s2p1_wide", True, 2, 70, 33, 4, 2, 1, (4, 4), 3),
+    ("convT2d_4s2p1_from1x1", True, 2, 10, 8, 4, 2, 1, (1, 1), 5),
+    ("convT2d_4s1p0_latent", True, 2, 9, 20, 4, 1, 0, (1, 1), 7),
+    ("convT2d_3s1p1", True, 2, 8, 3, 3, 1, 1, (10, 10), 2),
+    ("conv3d_4s122", False, 3, 3, 6, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 2),
+    ("conv3d_4s122_wide", False, 3, 36, 40, 4, (1, 2, 2), (0, 1, 1), (5, 4, 4), 2),
+    ("conv3d_head", False, 3, 20, 1, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 3),
+]
+
+
+@pytest.mark.parametrize("case", CONVS, ids=[c[0] for c in CONVS])
+@pytest.mark.parametrize("strided", [False, True])
+def test_conv_fwd_bwd(dev, case, strided):
+    from dcvgan_amd import ops
+    name, tr, nd, cin, cout, k, s, p, sp, n = case
+    g = torch.Generator().manual_seed(hash(name) % 10000)
+    s_t = (s,) * nd if isinstance(s, int) else s
+    p_t = (p,) * nd if isinstance(p, int) else p
+    wshape = ((cin, cout) if tr else (cout, cin)) + (k,) * nd
+    w = torch.randn(wshape, generator=g) * 0.2
+    if strided:  # channel-last memory viewed as NC..: the generators' output layout
+        x = torch.randn((n,) + sp + (cin,), generator=g).permute(0, nd + 1, *range(1, nd + 1))
+    else:
+        x = torch.randn((n, cin) + sp, generator=g)
+    x = x.requires_grad_(True); w = w.requires_grad_(True)
+    fn = {(False, 2): F.conv2d, (False, 3): F.conv3d, (True, 2): F.conv_transpose2d}[(tr, nd)]
+    y_ref = fn(x, w, None, s_t, p_t)
+    cot = torch.randn(y_ref.shape, generator=g)
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * cot).sum(), [x, w])
+
+    xd = x.detach().to(dev)
+    if strided:
+        xd = x.detach().permute(0, *range(2, nd + 2), 1).contiguous().to(dev).permute(0, nd + 1, *range(1, nd + 1))
+        assert (not xd.is_contiguous()) or cin == 1 or all(v == 1 for v in sp)
+    xd.requires_grad_(True)
+    wd = w.detach().to(dev).requires_grad_(True)
+    geom = ops.conv_geom(wd, s_t, p_t, tr)
+    y = ops.conv(xd, wd, geom)
+    assert y.shape == y_ref.shape
+    assert rel(y, y_ref) < TOL
+    gx, gw = torch.autograd.grad((y * cot.to(dev)).sum(), [xd, wd])
+    assert rel(gx, gx_ref) < TOL
+    assert rel(gw, gw_ref) < TOL
+
+
+def test_conv_fused_act(dev):
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 8, 8, generator=g, requires_grad=True); w = torch.randn(5, 3, 4, 4, generator=g, requires_grad=True)
+    y_ref = F.leaky_relu(F.conv2d(x, w, None, 2, 1), 0.2)
+    cot = torch.randn(y_ref.shape, generator=g)
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * cot).sum(), [x, w])
+    xd, wd = x.detach().to(dev).requires_grad_(True), w.detach().to(dev).requires_grad_(True)
+    y = ops.conv(xd, wd, ops.conv_geom(wd, (2, 2), (1, 1), False), ops.ACT_LEAKY, 0.2)
+    gx, gw = torch.autograd.grad((y * cot.to(dev)).sum(), [xd, wd])
+    assert rel(y, y_ref) < TOL and rel(gx, gx_ref) < TOL and rel(gw, gw_ref) < TOL
+
+
+@pytest.mark.parametrize("shape", [(3, 6, 8, 8), (2, 5, 4, 6, 6), (4, 7, 1, 1), (2, 3, 5, 3, 3)])
+@pytest.mark.parametrize("mode", ["train", "eval", "dropout"])
+def test_bn_act(dev, shape, mode):
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(shape, generator=g) * 1.7 + 0.4).requires_grad_(True)
+    Cn = shape[1]
+    gamma = (torch.rand(Cn, generator=g) + 0.5).requires_grad_(True); beta = torch.randn(Cn, generator=g).requires_grad_(True)
+    rm, rv = torch.randn(Cn, generator=g) * 0.1, torch.rand(Cn, generator=g) + 0.5
+    rm_d, rv_d = rm.clone().to(dev), rv.clone().to(dev)
+    training = mode != "eval"
+    mask = None
+    if mode == "dropout":
+        mask = (torch.rand(shape[0], Cn, generator=g) > 0.5).float().view(shape[0], Cn, *([1] * (len(shape) - 2))) * 2.0
+    h = F.batch_norm(x, rm, rv, gamma, beta, training, 0.1, 1e-5)
+    if mask is not None:
+        h = h * mask
+    y_ref = F.leaky_relu(h, 0.2)
+    cot = torch.randn(shape, generator=g)
+    g_ref = torch.autograd.grad((y_ref * cot).sum(), [x, gamma, beta])
+    xd = x.detach().to(dev).requires_grad_(True)
+    gd, bd = gamma.detach().to(dev).requires_grad_(True), beta.detach().to(dev).requires_grad_(True)
+    md = None if mask is None else mask.reshape(shape[0], Cn, 1, 1).to(dev)
+    y = ops.bn_act(xd, gd, bd, rm_d, rv_d, training, ops.ACT_LEAKY, 0.2, md)
+    assert rel(y, y_ref) < TOL
+    got = torch.autograd.grad((y * cot.to(dev)).sum(), [xd, gd, bd])
+    for a, b in zip(got, g_ref):
+        assert rel(a, b) < TOL
+    assert rel(rm_d, rm) < 1e-5 and rel(rv_d, rv) < 1e-5
+
+
+def test_act_cat_diff_noise(dev):
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 6, 8, 8, generator=g, requires_grad=True)
+    xd = x.detach().to(dev).requires_grad_(True)
+    for kind, ref in ((ops.ACT_TANH, torch.tanh), (ops.ACT_LEAKY, lambda t: F.leaky_relu(t, 0.01))):
+        y_ref = ref(x); cot = torch.randn(y_ref.shape, generator=g)
+        (gr,) = torch.autograd.grad((y_ref * cot).sum(), [x])
+        y = ops.act(xd, kind, 0.01)
+        (gg,) = torch.autograd.grad((y * cot.to(dev)).sum(), [xd])
+        assert rel(y, y_ref) < TOL and rel(gg, gr) < TOL
+    # temporal difference
+    y_ref = x[:, :, 1:] - x[:, :, :-1]; cot = torch.randn(y_ref.shape, generator=g)
+    (gr,) = torch.autograd.grad((y_ref * cot).sum(), [x])
+    y = ops.temporal_diff(xd)
+    (gg,) = torch.autograd.grad((y * cot.to(dev)).sum(), [xd])
+    assert rel(y, y_ref) < 1e-6 and rel(gg, gr) < 1e-6
+    # cat + injected noise
+    z = torch.randn(2, 4, 6, 8, 8, generator=g, requires_grad=True); zd = z.detach().to(dev).requires_grad_(True)
+    nz = torch.randn(2, 7, 6, 8, 8, generator=g)
+    y_ref = torch.cat([x, z], 1) + 0.3 * nz; cot = torch.randn(y_ref.shape, generator=g)
+    gr = torch.autograd.grad((y_ref * cot).sum(), [x, z])
+    y = ops.noise_add(ops.cat_channels(xd, zd), 0.3, nz.to(dev))
+    gg = torch.autograd.grad((y * cot.to(dev)).sum(), [xd, zd])
+    assert rel(y, y_ref) < 1e-6 and rel(gg[0], gr[0]) < 1e-6 and rel(gg[1], gr[1]) < 1e-6
+
+
+def test_device_rng_moments(dev):
+    from dcvgan_amd import ops
+    z = ops.normal((1 << 20,), dev, 1234, 0)
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    z2 = ops.normal((1 << 20,), dev, 1234, 1)
+    assert abs((z * z2).mean().item()) < 5e-3  # streams differ
+    assert torch.equal(z, ops.normal((1 << 20,), dev, 1234, 0))  # reproducible
+    x = torch.zeros(4, 3, 5, 16, 16, device=dev)
+    y = ops.noise_add(x, 0.5, None, 7, 3)
+    assert abs(y.std().item() - 0.5) < 2e-2
+    ystr = ops.noise_add(x.permute(0, 2, 1, 3, 4).contiguous().permute(0, 2, 1, 3, 4), 0.5, None, 7, 3)
+    assert torch.equal(y, ystr)  # the draw depends on the logical index, not on strides
+    m = ops.dropout2d_mask(512, 256, 0.5, dev, 9, 0)
+    assert set(m.unique().tolist()) == {0.0, 2.0} and abs(m.mean().item() - 1.0) < 2e-2
+
+
+@pytest.mark.parametrize("kind", range(5))
+def test_gan_loss(dev, kind):
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(kind)
+    y = (torch.randn(6, 4, 4, 4, generator=g) * 3).requires_grad_(True)
+    ref = [lambda t: F.binary_cross_entropy_with_logits(t, torch.ones_like(t), reduction="sum") / t.numel(),
+           lambda t: F.binary_cross_entropy_with_logits(t, torch.zeros_like(t), reduction="sum") / t.numel(),
+           lambda t: F.relu(1 - t).mean(), lambda t: F.relu(1 + t).mean(), lambda t: F.softplus(-t).mean()][kind]
+    v_ref = ref(y); (g_ref,) = torch.autograd.grad(v_ref * 1.5, [y])
+    yd = y.detach().to(dev).requires_grad_(True)
+    v = ops.gan_loss(yd, kind); (gg,) = torch.autograd.grad(v * 1.5, [yd])
+    assert abs(v.item() - v_ref.item()) < 1e-5 * max(1, abs(v_ref.item())) and rel(gg, g_ref) < 1e-5
+
+
+def test_gru_sequence(dev):
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(2)
+    T, B, dm = 16, 5, 10
+    cell = torch.nn.GRUCell(dm, dm)
+    e = torch.randn(T, B, dm, generator=g); h0 = torch.randn(B, dm, generator=g)
+    h = h0; hs = []
+    for t in range(T):
+        h = cell(e[t], h); hs.append(h)
+    out_ref = torch.stack(hs, 1); cot = torch.randn(out_ref.shape, generator=g)
+    params = [cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh]
+    g_ref = torch.autograd.grad((out_ref * cot).sum(), params)
+    pd = [p.detach().to(dev).requires_grad_(True) for p in params]
+    out = ops.gru_sequence(e.to(dev), h0.to(dev), *pd)
+    got = torch.autograd.grad((out * cot.to(dev)).sum(), pd)
+    assert rel(out, out_ref) < 1e-5
+    for a, b in zip(got, g_ref):
+        assert rel(a, b) < 1e-4
