@@ -1,0 +1,95 @@
+"""Executes torch.nn containers on the HIP kernels.
+
+The generators/discriminators keep their parameters in genuine nn.Conv2d /
+nn.ConvTranspose2d / nn.Conv3d / nn.BatchNorm{2,3}d / nn.GRUCell objects inside
+nn.Sequential containers, so ``state_dict`` keys, ``.apply(init_weights)``,
+``.to()``, pickling and torch optimisers behave exactly as with the reference.
+Only *execution* differs: ``run`` walks a Sequential and launches, per group of
+layers, the fused HIP op that implements it:
+
+    Noise                        -> noise_add   (Philox or injected sample)
+    Conv* [+ (Leaky)ReLU | Tanh] -> conv        (activation fused in the epilogue)
+    BatchNorm [+ Dropout2d] [+ (Leaky)ReLU] -> bn_act
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_CONVS = (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)
+_BNS = (nn.BatchNorm2d, nn.BatchNorm3d)
+
+
+def _act_of(layer):
+    """(code, slope) if `layer` is an activation the kernels can fuse, else None."""
+    if isinstance(layer, nn.LeakyReLU):
+        return ops.ACT_LEAKY, float(layer.negative_slope)
+    if isinstance(layer, nn.ReLU):
+        return ops.ACT_LEAKY, 0.0
+    if isinstance(layer, nn.Tanh):
+        return ops.ACT_TANH, 0.0
+    return None
+
+
+def geom_of(conv) -> "ops.ConvGeom":
+    if conv.bias is not None:
+        raise NotImplementedError("the DCVGAN layers are all bias-free")
+    if any(d != 1 for d in conv.dilation) or conv.groups != 1:
+        raise NotImplementedError("dilation/groups are not used by DCVGAN")
+    if isinstance(conv, nn.ConvTranspose2d) and any(o != 0 for o in conv.output_padding):
+        raise NotImplementedError("output_padding is not used by DCVGAN")
+    return ops.conv_geom(conv.weight, conv.stride, conv.padding, isinstance(conv, nn.ConvTranspose2d))
+
+
+def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None):
+    training = bn.training
+    mask = None
+    if dropout is not None and dropout.training:
+        mask = rng.dropout2d_mask(x.shape[0], x.shape[1], dropout.p, x.device)
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
+                      bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+
+
+def run(seq: nn.Sequential, x: torch.Tensor, rng) -> torch.Tensor:
+    layers = list(seq)
+    i, n = 0, len(layers)
+    while i < n:
+        layer = layers[i]
+        nxt = layers[i + 1] if i + 1 < n else None
+        if isinstance(layer, _CONVS):
+            fused = _act_of(nxt) if nxt is not None else None
+            if fused is not None:
+                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1])
+                i += 2
+            else:
+                x = ops.conv(x, layer.weight, geom_of(layer))
+                i += 1
+        elif isinstance(layer, _BNS):
+            j = i + 1
+            drop = None
+            if j < n and isinstance(layers[j], nn.Dropout2d):
+                drop = layers[j]
+                j += 1
+            fused = _act_of(layers[j]) if j < n else None
+            if fused is not None:
+                j += 1
+            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop)
+            i = j
+        elif _act_of(layer) is not None:
+            code, slope = _act_of(layer)
+            x = ops.act(x, code, slope)
+            i += 1
+        elif hasattr(layer, "use_noise") and hasattr(layer, "sigma"):  # discriminator.Noise
+            if layer.use_noise:
+                x = rng.noise_add(x, layer.sigma)
+            i += 1
+        elif isinstance(layer, nn.Softmax):  # segmentation head: outside the BASELINE configs
+            x = torch.softmax(x, layer.dim)
+            i += 1
+        else:
+            raise NotImplementedError(f"no HIP execution for layer {type(layer).__name__}")
+    return x

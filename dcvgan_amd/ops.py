@@ -6,6 +6,7 @@ computation of the G+D step below goes through libdcvgan_hip.so (native.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -23,6 +24,17 @@ def _dense(t: torch.Tensor) -> torch.Tensor:
     if any(s == 0 and n > 1 for s, n in zip(t.stride(), t.shape)):
         return t.contiguous()
     return t
+
+
+_POISON = bool(int(os.environ.get("DCV_DEBUG_POISON", "0")))
+
+
+def _empty(shape, device) -> torch.Tensor:
+    """Output allocation.  DCV_DEBUG_POISON=1 fills it with NaN so that an element a
+    kernel fails to write cannot hide behind recycled memory."""
+    if _POISON:
+        return torch.full(tuple(shape), float("nan"), dtype=torch.float32, device=device)
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
 
 
 def _ws(tag: str, nbytes: int, device) -> Tuple[C.c_void_p, int]:
@@ -65,7 +77,7 @@ class _Conv(Function):
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
         w = w.contiguous()
-        y = torch.empty(_out_shape(g, x), dtype=torch.float32, device=x.device)
+        y = _empty(_out_shape(g, x), x.device)
         xd, yd = dims5(x), dims5(y)
         L = lib()
         need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0)
@@ -84,20 +96,20 @@ class _Conv(Function):
         L = lib()
         dy = _dense(dy)
         if ctx.act != ACT_NONE:
-            dz = torch.empty_like(y)
+            dz = _empty(y.shape, y.device)
             dyd, yd = dims5(dy), dims5(y)
             check(L.dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dz), C.byref(yd), ctx.act, ctx.slope, stream_ptr()), "dcv_act_backward")
             dy = dz
         xd, dyd = dims5(x), dims5(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            dx = _empty(x.shape, x.device)
             dxd = dims5(dx)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), 0, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw = _empty(w.shape, w.device)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
@@ -118,8 +130,8 @@ class _BnAct(Function):
         N._require(x, "bn input")
         L = lib()
         Cn = x.shape[1]
-        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        stats = torch.empty(2, Cn, dtype=torch.float32, device=x.device)
+        y = _empty(x.shape, x.device)
+        stats = _empty((2, Cn), x.device)
         xd, yd = dims5(x), dims5(y)
         wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
         check(L.dcv_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
@@ -136,8 +148,8 @@ class _BnAct(Function):
         L = lib()
         dy = _dense(dy)
         Cn = x.shape[1]
-        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        dgb = torch.empty(2, Cn, dtype=torch.float32, device=x.device)
+        dx = _empty(x.shape, x.device)
+        dgb = _empty((2, Cn), x.device)
         dyd, xd, dxd = dims5(dy), dims5(x), dims5(dx)
         wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
         check(L.dcv_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta),
@@ -159,7 +171,7 @@ class _Act(Function):
     @staticmethod
     def forward(ctx, x, act: int, slope: float):
         N._require(x, "activation input")
-        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        y = _empty(x.shape, x.device)
         xd, yd = dims5(x), dims5(y)
         check(lib().dcv_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), act, slope, stream_ptr()), "dcv_act_forward")
         ctx.cfg = (act, slope)
@@ -171,7 +183,7 @@ class _Act(Function):
         (y,) = ctx.saved_tensors
         act, slope = ctx.cfg
         dy = _dense(dy)
-        dx = torch.empty_like(y)
+        dx = _empty(y.shape, y.device)
         dyd, yd = dims5(dy), dims5(y)
         check(lib().dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dx), C.byref(yd), act, slope, stream_ptr()), "dcv_act_backward")
         return dx, None, None
@@ -195,7 +207,7 @@ class _NoiseAdd(Function):
     @staticmethod
     def forward(ctx, x, sigma: float, sample, seed: int, offset: int):
         N._require(x, "noise input")
-        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        y = _empty(x.shape, x.device)
         if sample is not None:  # injected draw (parity tests)
             _axpby(x, 1.0, sample, sigma, y)
         else:
@@ -218,7 +230,7 @@ class _CatChannels(Function):
     def forward(ctx, a, b):
         N._require(a, "cat input"); N._require(b, "cat input")
         ca, cb = a.shape[1], b.shape[1]
-        out = torch.empty((a.shape[0], ca + cb) + tuple(a.shape[2:]), dtype=torch.float32, device=a.device)
+        out = _empty((a.shape[0], ca + cb) + tuple(a.shape[2:]), a.device)
         _axpby(a, 1.0, None, 0.0, out[:, :ca])
         _axpby(b, 1.0, None, 0.0, out[:, ca:])
         ctx.ca = ca
@@ -239,7 +251,7 @@ class _TemporalDiff(Function):
     def forward(ctx, x):
         N._require(x, "temporal_diff input")
         L = x.shape[2]
-        y = torch.empty((x.shape[0], x.shape[1], L - 1) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        y = _empty((x.shape[0], x.shape[1], L - 1) + tuple(x.shape[3:]), x.device)
         _axpby(x[:, :, 1:L], 1.0, x[:, :, 0:L - 1], -1.0, y)
         ctx.shape = tuple(x.shape)
         return y
@@ -248,7 +260,7 @@ class _TemporalDiff(Function):
     def backward(ctx, dy):
         dy = _dense(dy)
         L = ctx.shape[2]
-        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        dx = _empty(ctx.shape, dy.device)
         _axpby(dy[:, :, 0:1], -1.0, None, 0.0, dx[:, :, 0:1])
         _axpby(dy[:, :, L - 2:L - 1], 1.0, None, 0.0, dx[:, :, L - 1:L])
         if L > 2:
@@ -272,8 +284,8 @@ class _GanLoss(Function):
     def forward(ctx, y, kind: int):
         N._require(y, "loss input")
         yc = y.contiguous()
-        out = torch.empty((), dtype=torch.float32, device=y.device)
-        dy = torch.empty_like(yc)
+        out = _empty((), y.device)
+        dy = _empty(yc.shape, yc.device)
         check(lib().dcv_gan_loss(ptr(yc), yc.numel(), kind, ptr(out), 0, ptr(dy), stream_ptr()), "dcv_gan_loss")
         ctx.save_for_backward(dy)
         ctx.shape = tuple(y.shape)
@@ -300,8 +312,8 @@ class _GruSeq(Function):
         T, B, dm = e.shape
         e, h0 = e.contiguous(), h0.contiguous()
         w_ih, w_hh, b_ih, b_hh = w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()
-        out = torch.empty(B, T, dm, dtype=torch.float32, device=e.device)
-        gates = torch.empty(T, B, 4 * dm, dtype=torch.float32, device=e.device)
+        out = _empty((B, T, dm), e.device)
+        gates = _empty((T, B, 4 * dm), e.device)
         check(lib().dcv_gru_forward(ptr(e), ptr(h0), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(out), ptr(gates), T, B, dm, stream_ptr()), "dcv_gru_forward")
         ctx.save_for_backward(e, h0, out, gates, w_ih, w_hh)
         return out
@@ -311,9 +323,9 @@ class _GruSeq(Function):
         e, h0, out, gates, w_ih, w_hh = ctx.saved_tensors
         T, B, dm = e.shape
         dout = dout.contiguous()
-        dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
-        db_ih = torch.empty(3 * dm, dtype=torch.float32, device=e.device)
-        db_hh = torch.empty(3 * dm, dtype=torch.float32, device=e.device)
+        dw_ih, dw_hh = _empty(w_ih.shape, w_ih.device), _empty(w_hh.shape, w_hh.device)
+        db_ih = _empty((3 * dm,), e.device)
+        db_hh = _empty((3 * dm,), e.device)
         L = lib()
         wsp, wsn = _ws("gru", L.dcv_gru_workspace_bytes(B, dm), e.device)
         check(L.dcv_gru_backward(ptr(dout), ptr(e), ptr(h0), ptr(out), ptr(gates), ptr(w_ih), ptr(w_hh), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh),
@@ -330,12 +342,12 @@ def gru_sequence(e, h0, w_ih, w_hh, b_ih, b_hh):
 # random draws on the device
 # --------------------------------------------------------------------------- #
 def normal(shape, device, seed: int, offset: int) -> torch.Tensor:
-    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    out = _empty(tuple(shape), device)
     check(lib().dcv_normal_fill(ptr(out), out.numel(), int(seed), int(offset), stream_ptr()), "dcv_normal_fill")
     return out
 
 
 def dropout2d_mask(n: int, c: int, p: float, device, seed: int, offset: int) -> torch.Tensor:
-    out = torch.empty(n, c, 1, 1, dtype=torch.float32, device=device)
+    out = _empty((n, c, 1, 1), device)
     check(lib().dcv_dropout_mask(ptr(out), out.numel(), float(p), int(seed), int(offset), stream_ptr()), "dcv_dropout_mask")
     return out

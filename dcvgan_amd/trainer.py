@@ -1,0 +1,104 @@
+"""One G+D training iteration with the reference trainer's exact schedule.
+
+Restates /root/reference/src/trainer.py:279-363 (the reference file itself cannot
+ship: it imports evan / skvideo / colorlog / tensorboardX at module top, SURVEY
+§0 D8) over objects with the reference's duck types — so it also drives the
+reference's own classes, and a DCVGAN-style trainer drives ours.
+
+Kept quirks: D-phase fakes are NOT detached (the dead generator backward runs),
+``opt_ggen.step()`` is called twice, generators stay in whatever mode they were
+left in until the first G phase, update gating by num_gen_update / num_dis_update.
+Losses are returned as 0-d device tensors; ``sync_losses=True`` reproduces the
+reference's four ``.cpu().item()`` host syncs per iteration.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import discriminator as D
+from . import generator as G
+from . import loss as Lm
+from . import optim, util
+from .configs import StepConfig
+
+MODEL_NAMES = ("ggen", "cgen", "idis", "vdis", "gdis")
+
+
+def build_models(cfg: StepConfig, device=None) -> Dict[str, torch.nn.Module]:
+    """train.py:117-165: positional constructor wiring + init_weights."""
+    w = cfg.width
+    ggen = G.GeometricVideoGenerator(cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, cfg.geometric_info, w["ggen"], cfg.video_length)
+    cgen = G.ColorVideoGenerator(ggen.channel, cfg.dim_z_color, cfg.geometric_info, w["cgen"], cfg.video_length)
+    idis = D.ImageDiscriminator(ggen.channel, cgen.channel, cfg.use_noise["idis"], cfg.noise_sigma["idis"], w["idis"])
+    vdis = D.VideoDiscriminator(ggen.channel, cgen.channel, cfg.use_noise["vdis"], cfg.noise_sigma["vdis"], w["vdis"])
+    gdis = D.GradientDiscriminator(ggen.channel, cgen.channel, cfg.use_noise["gdis"], cfg.noise_sigma["gdis"], w["gdis"])
+    models = dict(ggen=ggen, cgen=cgen, idis=idis, vdis=vdis, gdis=gdis)
+    for m in models.values():
+        m.apply(util.init_weights)
+        m.to(device if device is not None else util.current_device())
+    return models
+
+
+def build_loss(cfg: StepConfig):
+    return Lm.AdversarialLoss() if cfg.loss == "adversarial-loss" else Lm.HingeLoss()
+
+
+def build_optimizers(cfg: StepConfig, models, data_parallel: bool = False):
+    """train.py:169-176."""
+    opts = {}
+    for name in MODEL_NAMES:
+        o = optim.Adam(models[name].parameters(), lr=cfg.lr[name], betas=(0.5, 0.999), weight_decay=cfg.decay[name])
+        opts[name] = optim.DataParallelAdam(o) if data_parallel else o
+    return opts
+
+
+class StepRunner:
+    def __init__(self, cfg: StepConfig, models, optimizers, loss, sync_losses: bool = False):
+        self.cfg, self.models, self.opt, self.loss = cfg, models, optimizers, loss
+        self.iteration = 0
+        self.sync_losses = sync_losses
+        if cfg.start_in_eval:  # trainer.py:266-267: log_samples/evaluate leave the generators in eval()
+            models["ggen"].eval(); models["cgen"].eval()
+
+    def step(self, xc_real: torch.Tensor, xg_real: torch.Tensor, t_rand: int):
+        c, m, o = self.cfg, self.models, self.opt
+        ggen, cgen, idis, vdis, gdis = (m[k] for k in MODEL_NAMES)
+        self.iteration += 1
+        # ---- discriminator phase (trainer.py:285-328) ----
+        for d in (idis, vdis, gdis):
+            d.train()
+        for d in (idis, vdis, gdis):
+            d.zero_grad()
+        y_real = (idis(xg_real[:, :, t_rand], xc_real[:, :, t_rand]), vdis(xg_real, xc_real), gdis(xg_real, xc_real))
+        xg_fake = ggen.sample_videos(c.batchsize)
+        xc_fake = cgen.forward_videos(xg_fake)
+        y_fake = (idis(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]), vdis(xg_fake, xc_fake), gdis(xg_fake, xc_fake))
+        loss_idis = self.loss.compute_dis_loss(y_real[0], y_fake[0])
+        loss_vdis = self.loss.compute_dis_loss(y_real[1], y_fake[1])
+        loss_gdis = self.loss.compute_dis_loss(y_real[2], y_fake[2])
+        loss_dis = loss_idis + loss_vdis + loss_gdis
+        if self.iteration % c.num_gen_update == 0:
+            loss_dis.backward()
+            o["idis"].step(); o["vdis"].step(); o["gdis"].step()
+        else:
+            loss_dis.detach_()
+        out = {"loss_idis": loss_idis.detach(), "loss_vdis": loss_vdis.detach(), "loss_gdis": loss_gdis.detach()}
+        if self.sync_losses:
+            out = {k: v.cpu().item() for k, v in out.items()}
+        del y_real, y_fake, xg_fake, xc_fake, loss_dis
+        # ---- generator phase (trainer.py:338-363) ----
+        ggen.train(); cgen.train()
+        ggen.zero_grad(); cgen.zero_grad()
+        xg_fake = ggen.sample_videos(c.batchsize)
+        xc_fake = cgen.forward_videos(xg_fake)
+        y_fake = (idis(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]), vdis(xg_fake, xc_fake), gdis(xg_fake, xc_fake))
+        loss_gen = self.loss.compute_gen_loss(*y_fake)
+        if self.iteration % c.num_dis_update == 0:
+            loss_gen.backward()
+            o["ggen"].step(); o["cgen"].step(); o["ggen"].step()  # ggen twice — trainer.py:357-359
+        else:
+            loss_gen.detach_()
+        out["loss_gen"] = loss_gen.detach().cpu().item() if self.sync_losses else loss_gen.detach()
+        return out

@@ -1,0 +1,25 @@
+"""Device pick and weight init, same contract as the reference's util.py:16-28,186-195."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+def current_device() -> torch.device:
+    """The process's current HIP device (cuda:0 unless torch.cuda.set_device was called — the
+    data-parallel launcher sets it to LOCAL_RANK before any model is built), else cpu."""
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def init_weights(layer) -> None:
+    """N(0, 0.02) for 2-D conv / transposed-conv weights, N(1, 0.02) / 0 for BatchNorm2d.
+    The test is on the exact type, so Conv3d, BatchNorm3d and GRUCell keep PyTorch's
+    default init — exactly what the reference does."""
+    kind = type(layer)
+    if kind is nn.Conv2d or kind is nn.ConvTranspose2d:
+        nn.init.normal_(layer.weight.data, 0.0, 0.02)
+    elif kind is nn.BatchNorm2d:
+        nn.init.normal_(layer.weight.data, 1.0, 0.02)
+        nn.init.constant_(layer.bias.data, 0.0)
