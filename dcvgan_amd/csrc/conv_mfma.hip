@@ -54,7 +54,8 @@ struct GatherArgs {
     const float* x;
     float* y;
     const float* wp;
-    const KEntry* ktab;
+    const int32_t* koff;    // per K row: BYTE offset added to the thread's base (SoA copy of KEntry.x_off * 4)
+    const uint32_t* ksel;   // per K row: tap-selection bits (KEntry.tapsel)
     int32_t M, OC, OCp, KIT;     // positions, out channels, packed pitch, 16-row K iterations
     FastDiv div_sp, div_hw, div_w;  // m -> (n, od, oh, ow): by OD*OH*OW, OH*OW, OW
     int32_t OD, OH, OW, pad0;
@@ -95,7 +96,6 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
     constexpr int XPT = 16 * BM / 256;        // gathered elements per thread per K step
-    constexpr int KSTEP = 256 / BM > 0 ? 256 / BM : 1;  // row stride between a thread's elements
     static_assert(WOC * WM == 4, "4 waves");
     static_assert(BM == 64 || BM == 128 || BM == 256, "BM");
     constexpr int WF4 = 16 * BN / 4;          // float4s in one W tile
@@ -117,12 +117,16 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
 
     // sample index of the block's first position: all 32-bit offsets are relative to it
     const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
-    const float* __restrict__ xblk = a.x + (int64_t)n0 * a.x_sn;
+    // Gathered operand through a raw buffer descriptor: an element outside the tensor (padding) is
+    // given the offset 0x80000000 >= num_records, for which the hardware returns 0 — no branch,
+    // no select, and hipcc counts the loads so they stay in flight under the MFMAs.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n0 * a.x_sn), 0, 0x80000000u, 0x00020000);
 
-    // ---- this thread's gather column ----
+    // ---- this thread's gather column; K rows ksub*XPT .. ksub*XPT + XPT-1 of every 16-row step ----
     const int lm = tid % BM;
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BM);
-    int xbase = 0;
+    int xbase4 = 0;
     uint32_t vmask = 0;
     {
         const int m = m0 + lm;
@@ -134,8 +138,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
             const uint32_t oh = fdiv(r, a.div_w);
             const uint32_t ow = r - oh * a.div_w.div;
             vmask = dim_mask(a.td, (int)od, 0) | dim_mask(a.th, (int)oh, 8) | dim_mask(a.tw, (int)ow, 16);
-            xbase = (int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd +
-                    ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw;
+            xbase4 = 4 * ((int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd +
+                          ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw);
         }
     }
 
@@ -151,14 +155,26 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
     float4 wv[WPT];
 
     auto load_tile = [&](int it) {
-        const KEntry* __restrict__ kt = a.ktab + it * 16;
+        // this wave's XPT index rows: wave-uniform addresses -> wide scalar loads, issued first
+        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4* __restrict__ ko4 = reinterpret_cast<const i32x4*>(a.koff + it * 16 + ksub * XPT);
+        const i32x4* __restrict__ ks4 = reinterpret_cast<const i32x4*>(a.ksel + it * 16 + ksub * XPT);
+        int32_t ko[XPT];
+        uint32_t ks[XPT];
+#pragma unroll
+        for (int q = 0; q < XPT / 4; ++q) {
+            const i32x4 o = ko4[q], t = ks4[q];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ko[4 * q + c] = o[c];
+                ks[4 * q + c] = (uint32_t)t[c];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const KEntry e = kt[ksub + KSTEP * i];
-            const bool ok = (vmask & e.tapsel) == e.tapsel;
-            const int off = ok ? xbase + e.x_off : 0;
-            const float v = xblk[off];
-            xv[i] = ok ? v : 0.f;
+            uint32_t vo = (uint32_t)(xbase4 + ko[i]);
+            vo = ((vmask & ks[i]) == ks[i]) ? vo : 0x80000000u;
+            xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) Xs[buf][ksub + KSTEP * i][lm] = xv[i];
+        for (int i = 0; i < XPT; ++i) Xs[buf][ksub * XPT + i][lm] = xv[i];
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
             const int f = tid + 256 * j;
@@ -260,8 +276,9 @@ struct WgradArgs {
     int32_t M, DC, J, DCp, Jp, chunk, pad0, pad1;
     FastDiv div_sp, div_hw, div_w;
     DimTaps td, th, tw;
-    int64_t d_sn, d_sc, d_sd, d_sh, d_sw;
-    int64_t g_sn, g_sd, g_sh, g_sw;
+    int64_t d_sn, g_sn;
+    int32_t d_sc4, d_sd, d_sh, d_sw;   // d_sc4: channel stride in BYTES
+    int32_t g_sd, g_sh, g_sw, pad2;
 };
 
 template <int TD, int TJ, int WD, int WJ>
@@ -286,21 +303,33 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
     const int m_end = min(a.M, m_begin + a.chunk);
     const int nit = (m_end > m_begin) ? (m_end - m_begin + 31) / 32 : 0;
 
-    // this thread's J rows are fixed for the whole reduction
-    int32_t goff[JPT];
+    // all 32-bit byte offsets are relative to the sample of the block's first position; elements
+    // outside the tensors (padding taps, ragged tails) get offset 0x80000000 -> hardware returns 0
+    const uint32_t nb = fdiv((uint32_t)(nit > 0 ? m_begin : 0), a.div_sp);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dptr + (int64_t)nb * a.d_sn), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x80000000u, 0x00020000);
+
+    // this thread's J rows (gathered channel, tap) are fixed for the whole reduction
+    int32_t goff4[JPT];
     uint32_t gsel[JPT];
 #pragma unroll
     for (int i = 0; i < JPT; ++i) {
         const int j = j0 + sub + 8 * i;
         if (j < a.J) {
             const KEntry e = a.jtab[j];
-            goff[i] = e.x_off;
+            goff4[i] = e.x_off * 4;
             gsel[i] = e.tapsel;
         } else {
-            goff[i] = 0;
+            goff4[i] = 0;
             gsel[i] = 1u << 31;
         }
     }
+    const int dcb4 = (d0 + sub) * a.d_sc4;   // byte offset of this thread's first dense channel
+    const int dstep4 = 8 * a.d_sc4;
+    uint32_t dcmask = 0;                      // bit i: dense channel d0 + sub + 8 i exists
+#pragma unroll
+    for (int i = 0; i < DPT; ++i)
+        if (d0 + sub + 8 * i < a.DC) dcmask |= 1u << i;
 
     f32x16 acc[TD][TJ];
 #pragma unroll
@@ -322,22 +351,20 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
         r -= pd * a.div_hw.div;
         const uint32_t ph = fdiv(r, a.div_w);
         const uint32_t pw = r - ph * a.div_w.div;
-        const float* __restrict__ dp = a.dptr + (int64_t)n * a.d_sn + (int64_t)pd * a.d_sd + (int64_t)ph * a.d_sh + (int64_t)pw * a.d_sw;
+        const int dbase4 = 4 * ((int)((int64_t)(n - nb) * a.d_sn) + (int)pd * a.d_sd + (int)ph * a.d_sh + (int)pw * a.d_sw) + dcb4;
+        const uint32_t dm = mok ? dcmask : 0u;
 #pragma unroll
         for (int i = 0; i < DPT; ++i) {
-            const int dc = d0 + sub + 8 * i;
-            const bool ok = mok && dc < a.DC;
-            const float v = dp[ok ? (int64_t)dc * a.d_sc : 0];
-            dv[i] = ok ? v : 0.f;
+            const uint32_t vo = ((dm >> i) & 1u) ? (uint32_t)(dbase4 + i * dstep4) : 0x80000000u;
+            dv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vo, 0, 0));
         }
         const uint32_t vmask = mok ? (dim_mask(a.td, (int)pd, 0) | dim_mask(a.th, (int)ph, 8) | dim_mask(a.tw, (int)pw, 16)) : 0u;
-        const int64_t gb = (int64_t)n * a.g_sn + (int64_t)((int)pd * a.td.mul + a.td.base) * a.g_sd +
-                           (int64_t)((int)ph * a.th.mul + a.th.base) * a.g_sh + (int64_t)((int)pw * a.tw.mul + a.tw.base) * a.g_sw;
+        const int gbase4 = 4 * ((int)((int64_t)(n - nb) * a.g_sn) + ((int)pd * a.td.mul + a.td.base) * a.g_sd +
+                                ((int)ph * a.th.mul + a.th.base) * a.g_sh + ((int)pw * a.tw.mul + a.tw.base) * a.g_sw);
 #pragma unroll
         for (int i = 0; i < JPT; ++i) {
-            const bool ok = (vmask & gsel[i]) == gsel[i];
-            const float v = a.gptr[ok ? gb + goff[i] : 0];
-            gv[i] = ok ? v : 0.f;
+            const uint32_t vo = ((vmask & gsel[i]) == gsel[i]) ? (uint32_t)(gbase4 + goff4[i]) : 0x80000000u;
+            gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo, 0, 0));
         }
     };
     auto store_tile = [&](int buf) {
@@ -403,7 +430,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 // host side: plans (index tables cached on the device per distinct geometry)
 // --------------------------------------------------------------------------- //
 struct DevTable {
-    KEntry* dev = nullptr;
+    KEntry* dev = nullptr;      // AoS (weight packing, wgrad J rows)
+    int32_t* koff = nullptr;    // SoA: byte offsets
+    uint32_t* ksel = nullptr;   // SoA: tap-selection bits
     int rows = 0;
 };
 
@@ -421,6 +450,18 @@ static int get_table(const std::string& key, const std::vector<KEntry>& host, De
     t.rows = (int)host.size();
     DCV_HIP_CHECK(hipMalloc((void**)&t.dev, host.size() * sizeof(KEntry)));
     DCV_HIP_CHECK(hipMemcpy(t.dev, host.data(), host.size() * sizeof(KEntry), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> off(host.size());
+        std::vector<uint32_t> sel(host.size());
+        for (size_t i = 0; i < host.size(); ++i) {
+            off[i] = host[i].x_off * 4;
+            sel[i] = host[i].tapsel;
+        }
+        DCV_HIP_CHECK(hipMalloc((void**)&t.koff, host.size() * sizeof(int32_t)));
+        DCV_HIP_CHECK(hipMalloc((void**)&t.ksel, host.size() * sizeof(uint32_t)));
+        DCV_HIP_CHECK(hipMemcpy(t.koff, off.data(), off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        DCV_HIP_CHECK(hipMemcpy(t.ksel, sel.data(), sel.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     g_tables[key] = t;
     *out = t;
     return DCV_OK;
@@ -501,7 +542,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                             KEntry e;
                             const int64_t xo = (int64_t)rc * xd.sc + (int64_t)c.taps[0].delta[ud] * xd.sd +
                                                (int64_t)c.taps[1].delta[uh] * xd.sh + (int64_t)c.taps[2].delta[uw] * xd.sw;
-                            if (xo > INT32_MAX || xo < INT32_MIN) return fail(DCV_EUNSUPPORTED, "%s: tensor too large for 32-bit offsets", tag);
+                            if (xo > INT32_MAX / 4 || xo < INT32_MIN / 4) return fail(DCV_EUNSUPPORTED, "%s: tensor too large for 32-bit offsets", tag);
                             e.x_off = (int32_t)xo;
                             e.tapsel = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
                             e.w_off = (int32_t)(rc * ws_r + ((int64_t)c.tap_k[0][ud] * KH + c.tap_k[1][uh]) * KW + c.tap_k[2][uw]);
@@ -528,7 +569,8 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.x = x;
         a.y = y;
         a.wp = wp;
-        a.ktab = tab.dev;
+        a.koff = tab.koff;
+        a.ksel = tab.ksel;
         a.M = (int)M64;
         a.OC = OC;
         a.OCp = OCp;
@@ -547,7 +589,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         {
             const int64_t per = (int64_t)c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
             const int64_t span = (tc.bm / per + 2) * (xd.sn < 0 ? -xd.sn : xd.sn) + (int64_t)RC * (xd.sc < 0 ? -xd.sc : xd.sc);
-            if (span >= (1ll << 31) || xd.sd > INT32_MAX / 64 || xd.sh > INT32_MAX / 64 || xd.sw > INT32_MAX / 64)
+            if (span >= (1ll << 29) || xd.sd > INT32_MAX / 256 || xd.sh > INT32_MAX / 256 || xd.sw > INT32_MAX / 256)
                 return fail(DCV_EUNSUPPORTED, "%s: input too large for 32-bit block offsets", tag);
         }
         a.x_sd = (int32_t)xd.sd;
@@ -722,7 +764,7 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
                     for (int uw = 0; uw < k[2]; ++uw) {
                         KEntry e;
                         const int64_t xo = (int64_t)gc * gd.sc + (int64_t)ud * gd.sd + (int64_t)uh * gd.sh + (int64_t)uw * gd.sw;
-                        if (xo > INT32_MAX) return fail(DCV_EUNSUPPORTED, "%s: tensor too large for 32-bit offsets", tag);
+                        if (xo > INT32_MAX / 4) return fail(DCV_EUNSUPPORTED, "%s: tensor too large for 32-bit offsets", tag);
                         e.x_off = (int32_t)xo;
                         e.tapsel = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
                         e.w_off = 0;
@@ -756,8 +798,16 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
         ts[d]->size = gext[d];
         for (int u = 0; u < k[d]; ++u) ts[d]->delta[u] = u;
     }
-    a.d_sn = dd.sn; a.d_sc = dd.sc; a.d_sd = dd.sd; a.d_sh = dd.sh; a.d_sw = dd.sw;
-    a.g_sn = gd.sn; a.g_sd = gd.sd; a.g_sh = gd.sh; a.g_sw = gd.sw;
+    {
+        // 32-bit byte offsets relative to the sample of a block's first position
+        const int64_t per = (int64_t)dd.d * dd.h * dd.w;
+        const int64_t samples = chunk / per + 2;
+        const int64_t dspan = samples * dd.sn + (int64_t)DCp * dd.sc, gspan = samples * gd.sn + (int64_t)GC * gd.sc;
+        if (dspan >= (1ll << 29) || gspan >= (1ll << 29)) return fail(DCV_EUNSUPPORTED, "%s: tensors too large for 32-bit block offsets", tag);
+    }
+    a.d_sn = dd.sn; a.g_sn = gd.sn;
+    a.d_sc4 = (int32_t)(dd.sc * 4); a.d_sd = (int32_t)dd.sd; a.d_sh = (int32_t)dd.sh; a.d_sw = (int32_t)dd.sw;
+    a.g_sd = (int32_t)gd.sd; a.g_sh = (int32_t)gd.sh; a.g_sw = (int32_t)gd.sw;
     if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 64) launch_wgrad<2, 1, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 64 && tc.bj == 256) launch_wgrad<2, 2, 1, 4>(a, tiles, S2, stream);
