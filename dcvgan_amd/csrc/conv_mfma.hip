@@ -65,6 +65,10 @@ struct GatherArgs {
     int64_t y_sn, y_sc, y_sd, y_sh, y_sw, y_off;
     int32_t act, accumulate;
     float slope, pad2;
+    // split-K: blockIdx.y handles K steps [y*kper, (y+1)*kper) and writes raw partial sums to
+    // slab[y][oc][m] (pitch Mp); splitk_reduce_kernel sums them in order and does the epilogue.
+    float* slab;
+    int32_t kper, Mp;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -198,14 +202,16 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
         }
     };
 
-    load_tile(0);
+    const int it0 = a.slab ? blockIdx.y * a.kper : 0;
+    const int it1 = a.slab ? min(a.KIT, it0 + a.kper) : a.KIT;
+    load_tile(it0);
     store_tile(0);
     __syncthreads();
 
     const int l31 = lane & 31, lhi = lane >> 5;
-    for (int it = 0; it < a.KIT; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < a.KIT) load_tile(it + 1);
+    for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) & 1;
+        if (it + 1 < it1) load_tile(it + 1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int k = 2 * ks + lhi;
@@ -220,8 +226,22 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < a.KIT) store_tile(buf ^ 1);
+        if (it + 1 < it1) store_tile(buf ^ 1);
         __syncthreads();
+    }
+
+    if (a.slab) {  // raw partial sums, GEMM layout, padded so no bounds checks
+        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    sl[(int64_t)oc * a.Mp + m0 + (wm * TM + j) * 32 + l31] = acc[i][j][r];
+                }
+        return;
     }
 
     // ---- epilogue: acc[i][j][r] -> oc = .. + (r&3) + 8*(r>>2) + 4*lhi, m = .. + l31 ----
@@ -250,6 +270,104 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
             }
         }
     }
+}
+
+// y = act( sum_s slab[s][oc][m] (+ y) ), scattered to the NCDHW output; fixed summation order.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GatherArgs a, int S) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int m = (int)(idx % a.Mp), oc = (int)(idx / a.Mp);
+    if (m >= a.M || oc >= a.OC) return;
+    const float* __restrict__ p = a.slab + (int64_t)oc * a.Mp + m;
+    const int64_t stride = (int64_t)a.OCp * a.Mp;
+    float v = 0.f;
+    for (int k = 0; k < S; ++k) v += p[k * stride];
+    const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+    uint32_t r0 = (uint32_t)m - n * a.div_sp.div;
+    const uint32_t od = fdiv(r0, a.div_hw);
+    r0 -= od * a.div_hw.div;
+    const uint32_t oh = fdiv(r0, a.div_w);
+    const uint32_t ow = r0 - oh * a.div_w.div;
+    float* q = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)oc * a.y_sc + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+    if (a.accumulate) v += *q;
+    *q = apply_act(v, a.act, a.slope);
+}
+
+// --------------------------------------------------------------------------- //
+// thin gather: OC <= 4 (RGB / depth / flow heads and stems' data gradients, D logits).
+// A 32-wide MFMA tile would waste >= 7/8 of the matrix pipe on these, so they run as direct
+// FMAs: 64 positions per block (lanes along m, coalesced), the block's 4 waves split the K
+// range, weights Wp[k][4] and the index rows are wave-uniform scalar loads.  With a slab
+// (blockIdx.y = K split) the partial sums go through splitk_reduce_kernel.
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void thin_gather_kernel(const GatherArgs a) {
+    __shared__ float red[3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 64;
+    const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n0 * a.x_sn), 0, 0x80000000u, 0x00020000);
+    const int m = m0 + lane;
+    int xbase4 = 0;
+    uint32_t vmask = 0;
+    uint32_t n = 0, od = 0, oh = 0, ow = 0;
+    if (m < a.M) {
+        n = fdiv((uint32_t)m, a.div_sp);
+        uint32_t r = (uint32_t)m - n * a.div_sp.div;
+        od = fdiv(r, a.div_hw);
+        r -= od * a.div_hw.div;
+        oh = fdiv(r, a.div_w);
+        ow = r - oh * a.div_w.div;
+        vmask = dim_mask(a.td, (int)od, 0) | dim_mask(a.th, (int)oh, 8) | dim_mask(a.tw, (int)ow, 16);
+        xbase4 = 4 * ((int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd +
+                      ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw);
+    }
+    // this block's K rows (groups of 4), then this wave's share of them
+    const int g_all = a.KIT * 4;
+    const int gb0 = a.slab ? blockIdx.y * a.kper * 4 : 0;
+    const int gb1 = a.slab ? min(g_all, gb0 + a.kper * 4) : g_all;
+    const int gper = (gb1 - gb0 + 3) / 4;
+    const int g0 = gb0 + wave * gper, g1 = min(gb1, g0 + gper);
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int g = g0; g < g1; ++g) {
+        const i32x4 ko = *reinterpret_cast<const i32x4*>(a.koff + 4 * g);
+        const i32x4 ks = *reinterpret_cast<const i32x4*>(a.ksel + 4 * g);
+        float xv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t vo = (uint32_t)(xbase4 + ko[c]);
+            vo = ((vmask & (uint32_t)ks[c]) == (uint32_t)ks[c]) ? vo : 0x80000000u;
+            xv[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, 0, 0));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 w = *reinterpret_cast<const float4*>(a.wp + (int64_t)(4 * g + c) * 4);
+            acc0 += w.x * xv[c]; acc1 += w.y * xv[c]; acc2 += w.z * xv[c]; acc3 += w.w * xv[c];
+        }
+    }
+    if (wave > 0) { red[wave - 1][0][lane] = acc0; red[wave - 1][1][lane] = acc1; red[wave - 1][2][lane] = acc2; red[wave - 1][3][lane] = acc3; }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { acc0 += red[w][0][lane]; acc1 += red[w][1][lane]; acc2 += red[w][2][lane]; acc3 += red[w][3][lane]; }
+    const float out[4] = {acc0, acc1, acc2, acc3};
+    if (a.slab) {
+        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sl[(int64_t)c * a.Mp + m] = out[c];   // Mp is a multiple of 64
+        return;
+    }
+    if (m >= a.M) return;
+    float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c < a.OC) {
+            float v = out[c];
+            float* q = yb + (int64_t)c * a.y_sc;
+            if (a.accumulate) v += *q;
+            *q = apply_act(v, a.act, a.slope);
+        }
 }
 
 // Wp[k][oc] = w[oc * ws_o + ktab[k].w_off]   (zero for padding rows / channels)
@@ -282,13 +400,15 @@ struct WgradArgs {
 };
 
 template <int TD, int TJ, int WD, int WJ>
-__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (TD * TJ >= 4 ? 2 : 3)) void wgrad_gemm_kernel(const WgradArgs a) {
     constexpr int BD = 32 * TD * WD;
     constexpr int BJ = 32 * TJ * WJ;
     constexpr int DPT = BD / 8, JPT = BJ / 8;  // elements per thread per step
     static_assert(WD * WJ == 4, "4 waves");
-    __shared__ float Ds[2][32][BD + 1];
-    __shared__ float Gs[2][32][BJ + 1];
+    // ONE staging buffer (two barriers per 32-position step): half the LDS of a double buffer, so
+    // 2-4 blocks share a CU and cover each other's barriers and global-load latency.
+    __shared__ float Ds[32][BD + 1];
+    __shared__ float Gs[32][BJ + 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -367,39 +487,41 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const WgradArgs a) {
             gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo, 0, 0));
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < DPT; ++i) Ds[buf][ml][sub + 8 * i] = dv[i];
+        for (int i = 0; i < DPT; ++i) Ds[ml][sub + 8 * i] = dv[i];
 #pragma unroll
-        for (int i = 0; i < JPT; ++i) Gs[buf][ml][sub + 8 * i] = gv[i];
+        for (int i = 0; i < JPT; ++i) Gs[ml][sub + 8 * i] = gv[i];
     };
 
     if (nit > 0) {
         load_tile(0);
-        store_tile(0);
+        store_tile();
     }
     __syncthreads();
 
     const int l31 = lane & 31, lhi = lane >> 5;
     for (int it = 0; it < nit; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nit) load_tile(it + 1);
+        if (it + 1 < nit) load_tile(it + 1);   // global loads stay in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int k = 2 * ks + lhi;
             float af[TD], bf[TJ];
 #pragma unroll
-            for (int i = 0; i < TD; ++i) af[i] = Ds[buf][k][(wd * TD + i) * 32 + l31];
+            for (int i = 0; i < TD; ++i) af[i] = Ds[k][(wd * TD + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = Gs[buf][k][(wj * TJ + j) * 32 + l31];
+            for (int j = 0; j < TJ; ++j) bf[j] = Gs[k][(wj * TJ + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < nit) store_tile(buf ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                        // every wave has read the tile
+        if (it + 1 < nit) store_tile();
+        __syncthreads();                        // next tile visible
     }
 
     float* __restrict__ out = a.slab + (int64_t)blockIdx.y * a.DCp * a.Jp;
@@ -481,14 +603,27 @@ struct TileCfg {
 };
 
 static TileCfg pick_gather_tile(int OC) {
+    if (OC <= 4) return {4, 64};  // thin_gather_kernel
     if (OC > 64) return {128, 128};
     if (OC > 32) return {64, 256};
     return {32, 256};
 }
 
 template <int TOC, int TM, int WOC, int WM>
-static void launch_gather(const GatherArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM>), dim3(grid), dim3(256), 0, s, a);
+static void launch_gather(const GatherArgs& a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM>), grid, dim3(256), 0, s, a);
+}
+
+// K splits for a gather launch of `blocks` workgroups over KIT 16-row steps: fill ~2 waves of
+// 256 CUs x 3 blocks, keep >= 8 steps per split (thin kernel: >= 16, its 4 waves split again).
+static int gather_splits(int blocks, int KIT, bool thin) {
+    const int min_steps = thin ? 16 : 8;
+    if (blocks >= 384 || KIT < 2 * min_steps) return 1;
+    int ks = (768 + blocks - 1) / blocks;
+    const int maxks = KIT / min_steps;
+    if (ks > maxks) ks = maxks;
+    if (ks > 64) ks = 64;
+    return ks < 1 ? 1 : ks;
 }
 
 // The generic driver: reduce over `RC` channels of tensor `x` (dims xd) into `OC`
@@ -553,11 +688,20 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             int rc_ = get_table(key, host, &tab);
             if (rc_ != DCV_OK) return rc_;
         }
+        // ---- split-K decision: under-filled grids with a long K loop ----
+        const int Mp = (int)((M64 + tc.bm - 1) / tc.bm * tc.bm);
+        const int blocks = (OCp / tc.bn) * (Mp / tc.bm);
+        const int KS = gather_splits(blocks, KIT, tc.bn == 4);
+        const int kper = (KIT + KS - 1) / KS;
+        const int KS2 = (KIT + kper - 1) / kper;
         // ---- pack weights ----
         const size_t wp_bytes = align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
-        if (ws_off + wp_bytes > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, ws_off + wp_bytes, ws_bytes);
+        const size_t slab_bytes = KS2 > 1 ? align_up((size_t)KS2 * OCp * Mp * sizeof(float), 256) : 0;
+        if (ws_off + wp_bytes + slab_bytes > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, ws_off + wp_bytes + slab_bytes, ws_bytes);
         float* wp = reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off);
         ws_off += wp_bytes;
+        float* slab = KS2 > 1 ? reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off) : nullptr;
+        ws_off += slab_bytes;
         {
             const int64_t tot = (int64_t)KIT * 16 * OCp;
             hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, wp, tab.dev, KIT * 16, OC, OCp, ws_o);
@@ -604,23 +748,39 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.act = act;
         a.slope = slope;
         a.accumulate = accumulate;
-        const int grid = (OCp / tc.bn) * ((a.M + tc.bm - 1) / tc.bm);
-        if (tc.bn == 128) launch_gather<2, 2, 2, 2>(a, grid, stream);
+        a.slab = slab;
+        a.kper = kper;
+        a.Mp = Mp;
+        const dim3 grid((unsigned)blocks, (unsigned)KS2);
+        if (tc.bn == 4) hipLaunchKernelGGL(thin_gather_kernel, grid, dim3(256), 0, stream, a);
+        else if (tc.bn == 128) launch_gather<2, 2, 2, 2>(a, grid, stream);
         else if (tc.bn == 64) launch_gather<2, 2, 1, 4>(a, grid, stream);
         else launch_gather<1, 2, 1, 4>(a, grid, stream);
         DCV_LAUNCH_CHECK();
+        if (KS2 > 1) {
+            const int64_t tot = (int64_t)OC * Mp;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, a, KS2);
+            DCV_LAUNCH_CHECK();
+        }
     }
     return DCV_OK;
 }
 
-static size_t gather_ws_bytes(int RC, int OC, const std::vector<GatherClass>& classes) {
+static size_t gather_ws_bytes(int RC, int OC, int N, const std::vector<GatherClass>& classes) {
     const TileCfg tc = pick_gather_tile(OC);
     const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
     size_t tot = 0;
     for (const GatherClass& c : classes) {
         const int T = c.taps[0].n * c.taps[1].n * c.taps[2].n;
+        if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
         const int64_t K = (int64_t)RC * T;
-        tot += align_up((size_t)((K + 15) / 16) * 16 * OCp * sizeof(float), 256);
+        const int KIT = (int)((K + 15) / 16);
+        tot += align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
+        const int64_t M64 = (int64_t)N * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+        const int64_t Mp = (M64 + tc.bm - 1) / tc.bm * tc.bm;
+        const int blocks = (int)((OCp / tc.bn) * (Mp / tc.bm));
+        const int KS = gather_splits(blocks, KIT, tc.bn == 4);
+        if (KS > 1) tot += align_up((size_t)KS * OCp * Mp * sizeof(float), 256);
     }
     return tot + 256;
 }
@@ -869,7 +1029,7 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
             ws_r = (int64_t)OC * T;
         }
         if (need_only) {
-            *need_only = gather_ws_bytes(RC, OC, cls);
+            *need_only = gather_ws_bytes(RC, OC, dst.n, cls);
             return DCV_OK;
         }
         if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
