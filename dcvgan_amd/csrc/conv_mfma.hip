@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t dim_mask(const DimTaps& t, int o, int shift)
 // positions, K step 16.
 // --------------------------------------------------------------------------- //
 template <int TOC, int TM, int WOC, int WM>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a) {
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
     constexpr int XPT = 16 * BM / 256;        // gathered elements per thread per K step
@@ -212,20 +212,35 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GatherArgs a) {
     for (int it = it0; it < it1; ++it) {
         const int buf = (it - it0) & 1;
         if (it + 1 < it1) load_tile(it + 1);
+        // a wave that has entered its MFMA phase outranks the co-resident waves (other blocks) that are
+        // still issuing loads/stores: phases rotate instead of interleaving into a convoy
+        __builtin_amdgcn_s_setprio(2);
+        // fragments of k-step ks+1 are read from LDS while the MFMAs of step ks run
+        float af[2][TOC], bf[2][TM];
+#pragma unroll
+        for (int i = 0; i < TOC; ++i) af[0][i] = Ws[buf][lhi][(woc * TOC + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) bf[0][j] = Xs[buf][lhi][(wm * TM + j) * 32 + l31];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const int k = 2 * ks + lhi;
-            float af[TOC], bf[TM];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 8) {
+                const int k = 2 * (ks + 1) + lhi;
 #pragma unroll
-            for (int i = 0; i < TOC; ++i) af[i] = Ws[buf][k][(woc * TOC + i) * 32 + l31];
+                for (int i = 0; i < TOC; ++i) af[nxt][i] = Ws[buf][k][(woc * TOC + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = Xs[buf][k][(wm * TM + j) * 32 + l31];
+                for (int j = 0; j < TM; ++j) bf[nxt][j] = Xs[buf][k][(wm * TM + j) * 32 + l31];
+            }
 #pragma unroll
             for (int i = 0; i < TOC; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            // pin the order hipcc would otherwise undo: next step's LDS reads, THEN this step's MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (it + 1 < it1) store_tile(buf ^ 1);
         __syncthreads();
     }
@@ -504,20 +519,31 @@ __global__ __launch_bounds__(256, (TD * TJ >= 4 ? 2 : 3)) void wgrad_gemm_kernel
     for (int it = 0; it < nit; ++it) {
         if (it + 1 < nit) load_tile(it + 1);   // global loads stay in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);
+        float af[2][TD], bf[2][TJ];
+#pragma unroll
+        for (int i = 0; i < TD; ++i) af[0][i] = Ds[lhi][(wd * TD + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bf[0][j] = Gs[lhi][(wj * TJ + j) * 32 + l31];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const int k = 2 * ks + lhi;
-            float af[TD], bf[TJ];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 16) {
+                const int k = 2 * (ks + 1) + lhi;
 #pragma unroll
-            for (int i = 0; i < TD; ++i) af[i] = Ds[k][(wd * TD + i) * 32 + l31];
+                for (int i = 0; i < TD; ++i) af[nxt][i] = Ds[k][(wd * TD + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) bf[j] = Gs[k][(wj * TJ + j) * 32 + l31];
+                for (int j = 0; j < TJ; ++j) bf[nxt][j] = Gs[k][(wj * TJ + j) * 32 + l31];
+            }
 #pragma unroll
             for (int i = 0; i < TD; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TD + TJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TD * TJ, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                        // every wave has read the tile
         if (it + 1 < nit) store_tile();
@@ -986,6 +1012,33 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
 using namespace dcv;
 
 extern "C" {
+
+// Diagnostics: resident workgroups per CU (HIP occupancy API) and register/LDS use of each GEMM
+// kernel instantiation, as text.  Used by tools/ and DESIGN.md; not part of the hot path.
+int dcv_debug_kernel_info(char* buf, size_t n) {
+    struct Item { const char* name; const void* fn; };
+    const Item items[] = {
+        {"gather<2,2,2,2>", (const void*)gather_gemm_kernel<2, 2, 2, 2>}, {"gather<2,2,1,4>", (const void*)gather_gemm_kernel<2, 2, 1, 4>},
+        {"gather<1,2,1,4>", (const void*)gather_gemm_kernel<1, 2, 1, 4>}, {"thin_gather", (const void*)thin_gather_kernel},
+        {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2>},
+        {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4>},
+        {"wgrad<1,2,1,4>", (const void*)wgrad_gemm_kernel<1, 2, 1, 4>}, {"wgrad<1,1,1,4>", (const void*)wgrad_gemm_kernel<1, 1, 1, 4>},
+    };
+    size_t off = 0;
+    for (const Item& it : items) {
+        int blocks = -1;
+        hipFuncAttributes at;
+        memset(&at, 0, sizeof(at));
+        hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, it.fn, 256, 0);
+        hipError_t e2 = hipFuncGetAttributes(&at, it.fn);
+        int w = snprintf(buf + off, off < n ? n - off : 0, "%s: blocks/CU=%d regs=%d lds=%zu scratch=%zu (%s)\n", it.name, blocks, at.numRegs,
+                         (size_t)at.sharedSizeBytes, (size_t)at.localSizeBytes, (e1 == hipSuccess && e2 == hipSuccess) ? "ok" : "query failed");
+        if (w < 0) break;
+        off += (size_t)w;
+        if (off >= n) break;
+    }
+    return (int)off;
+}
 
 const char* dcv_last_error(void) { return g_err; }
 int dcv_version(void) { return 1; }

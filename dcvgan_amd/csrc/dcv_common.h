@@ -65,7 +65,7 @@ inline FastDiv make_fastdiv(uint32_t d) {
 #ifdef __HIPCC__
 namespace dcv {
 // n / d for the FastDiv above (d == 1 handled by mul == 0 convention)
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) {
     if (f.div == 1) return n;
     uint32_t t = __umulhi(n, f.mul);
     return (t + ((n - t) >> 1)) >> (f.shift - 1);

@@ -46,6 +46,7 @@ _SIGS = {
     "dcv_last_error": (C.c_char_p, []),
     "dcv_version": (C.c_int, []),
     "dcv_launch_count": (C.c_uint64, []),
+    "dcv_debug_kernel_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dcv_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
     "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),

@@ -63,6 +63,8 @@ int dcv_version(void);
 /* number of kernel launches issued through this library so far (tests use it to
  * prove the HIP path, not a fallback, did the work) */
 uint64_t dcv_launch_count(void);
+/* diagnostics text: resident workgroups/CU, registers, LDS of every GEMM kernel (needs a GPU) */
+int dcv_debug_kernel_info(char* buf, size_t n);
 
 /* ---- convolutions ------------------------------------------------------- *
  * Replace nn.Conv2d (generator.py:174,204; discriminator.py:83,89,95-101),
