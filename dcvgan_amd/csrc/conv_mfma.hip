@@ -35,6 +35,14 @@ std::atomic<uint64_t> g_launches{0};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef DCV_STAMP
+// diagnostic build only: per-wave cycle totals of the K-loop segments (never in the shipped library)
+__device__ unsigned long long g_stamp[4096][4][6];
+#define STAMP(var) unsigned long long var = clock64(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAMP(var) __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // one row of the K (gather) or J (wgrad) index table
 struct KEntry {
     int32_t x_off;    // element offset added to the thread's base: chan*sc + tap deltas
@@ -69,6 +77,12 @@ struct GatherArgs {
     // slab[y][oc][m] (pitch Mp); splitk_reduce_kernel sums them in order and does the epilogue.
     float* slab;
     int32_t kper, Mp;
+    // structured K walk (regular geometries): the 16 rows of a K step have iteration-invariant byte
+    // offsets s_local[r] / tap bits s_sel[r]; step `it` adds the scalar (it >> s_log2p) * s_stepA +
+    // (it & ((1 << s_log2p) - 1)) * s_stepD.  No index-table reads, no per-element VALU in the loop.
+    int32_t structured, s_log2p, s_stepA, s_stepD;
+    int32_t s_local[16];
+    uint32_t s_sel[16];
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -95,7 +109,7 @@ __device__ __forceinline__ uint32_t dim_mask(const DimTaps& t, int o, int shift)
 // TOC x TM MFMA tiles of 32x32.  BN = 32*TOC*WOC output channels, BM = 32*TM*WM
 // positions, K step 16.
 // --------------------------------------------------------------------------- //
-template <int TOC, int TM, int WOC, int WM>
+template <int TOC, int TM, int WOC, int WM, bool STRUCT>
 __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a) {
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
@@ -158,7 +172,24 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
     float xv[XPT];
     float4 wv[WPT];
 
+    // structured walk: per-thread voffsets fixed for the whole K loop (padding folded in as 0x80000000)
+    uint32_t vloc[STRUCT ? XPT : 1];
+    if constexpr (STRUCT) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int r = ksub * XPT + i;
+            const uint32_t sel = a.s_sel[r];
+            vloc[i] = ((vmask & sel) == sel) ? (uint32_t)(xbase4 + a.s_local[r]) : 0x80000000u;
+        }
+    }
+
     auto load_tile = [&](int it) {
+        if constexpr (STRUCT) {
+            const int soff = (it >> a.s_log2p) * a.s_stepA + (it & ((1 << a.s_log2p) - 1)) * a.s_stepD;
+#pragma unroll
+            for (int i = 0; i < XPT; ++i)
+                xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vloc[i], soff, 0));
+        } else {
         // this wave's XPT index rows: wave-uniform addresses -> wide scalar loads, issued first
         typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
         const i32x4* __restrict__ ko4 = reinterpret_cast<const i32x4*>(a.koff + it * 16 + ksub * XPT);
@@ -179,6 +210,7 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
             uint32_t vo = (uint32_t)(xbase4 + ko[i]);
             vo = ((vmask & ks[i]) == ks[i]) ? vo : 0x80000000u;
             xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, 0, 0));
+        }
         }
 #pragma unroll
         for (int j = 0; j < WPT; ++j) {
@@ -209,9 +241,17 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
     __syncthreads();
 
     const int l31 = lane & 31, lhi = lane >> 5;
+#ifdef DCV_STAMP
+    unsigned long long seg0 = 0, seg1 = 0, seg2 = 0, seg3 = 0;
+    const unsigned long long tstart = clock64();
+#endif
     for (int it = it0; it < it1; ++it) {
         const int buf = (it - it0) & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(t0);
         if (it + 1 < it1) load_tile(it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(t1);
         // a wave that has entered its MFMA phase outranks the co-resident waves (other blocks) that are
         // still issuing loads/stores: phases rotate instead of interleaving into a convoy
         __builtin_amdgcn_s_setprio(2);
@@ -241,9 +281,22 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
             __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);
         }
         __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(t2);
         if (it + 1 < it1) store_tile(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(t3);
         __syncthreads();
+#ifdef DCV_STAMP
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long t4 = clock64(); seg0 += t1 - t0; seg1 += t2 - t1; seg2 += t3 - t2; seg3 += t4 - t3; }
+#endif
     }
+#ifdef DCV_STAMP
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned long long* g = g_stamp[blockIdx.x][wave];
+        g[0] = seg0; g[1] = seg1; g[2] = seg2; g[3] = seg3; g[4] = clock64() - tstart; g[5] = (unsigned long long)(it1 - it0);
+    }
+#endif
 
     if (a.slab) {  // raw partial sums, GEMM layout, padded so no bounds checks
         float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
@@ -637,7 +690,8 @@ static TileCfg pick_gather_tile(int OC) {
 
 template <int TOC, int TM, int WOC, int WM>
 static void launch_gather(const GatherArgs& a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM>), grid, dim3(256), 0, s, a);
+    if (a.structured) hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, false>), grid, dim3(256), 0, s, a);
 }
 
 // K splits for a gather launch of `blocks` workgroups over KIT 16-row steps: fill ~2 waves of
@@ -777,6 +831,36 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.slab = slab;
         a.kper = kper;
         a.Mp = Mp;
+        // ---- structured K walk? (K order is (rc, ud, uh, uw), 16 rows per step) ----
+        {
+            const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n, THW = nh * nw;
+            const int64_t sc4 = xd.sc * 4;
+            a.structured = 0;
+            if (16 % T == 0 && RC % (16 / T) == 0 && sc4 * (16 / T) < (1ll << 30)) {
+                // every step covers 16/T whole channels with all T taps
+                a.structured = 1;
+                a.s_log2p = 0;
+                a.s_stepA = (int32_t)(sc4 * (16 / T));
+                a.s_stepD = 0;
+                for (int r = 0; r < 16; ++r) {
+                    const int rcl = r / T, t = r % T, ud = t / THW, uh = (t / nw) % nh, uw = t % nw;
+                    a.s_local[r] = (int32_t)(4 * (rcl * xd.sc + c.taps[0].delta[ud] * xd.sd + c.taps[1].delta[uh] * xd.sh + c.taps[2].delta[uw] * xd.sw));
+                    a.s_sel[r] = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
+                }
+            } else if (THW == 16 && (nd == 2 || nd == 4 || nd == 8) && c.taps[0].mul == 1 && c.taps[0].base == 0 &&
+                       c.taps[0].delta[nd - 1] == nd - 1 && c.o_ext[0] + nd - 1 <= c.taps[0].size && sc4 < (1ll << 30)) {
+                // 4x4 inner taps, step = (channel, depth tap); depth taps never leave the tensor (no depth padding)
+                a.structured = 1;
+                a.s_log2p = nd == 2 ? 1 : nd == 4 ? 2 : 3;
+                a.s_stepA = (int32_t)sc4;
+                a.s_stepD = (int32_t)(4 * xd.sd);
+                for (int r = 0; r < 16; ++r) {
+                    const int uh = r / nw, uw = r % nw;
+                    a.s_local[r] = (int32_t)(4 * (c.taps[1].delta[uh] * xd.sh + c.taps[2].delta[uw] * xd.sw));
+                    a.s_sel[r] = (1u << (8 + uh)) | (1u << (16 + uw));
+                }
+            }
+        }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         if (tc.bn == 4) hipLaunchKernelGGL(thin_gather_kernel, grid, dim3(256), 0, stream, a);
         else if (tc.bn == 128) launch_gather<2, 2, 2, 2>(a, grid, stream);
@@ -1018,8 +1102,9 @@ extern "C" {
 int dcv_debug_kernel_info(char* buf, size_t n) {
     struct Item { const char* name; const void* fn; };
     const Item items[] = {
-        {"gather<2,2,2,2>", (const void*)gather_gemm_kernel<2, 2, 2, 2>}, {"gather<2,2,1,4>", (const void*)gather_gemm_kernel<2, 2, 1, 4>},
-        {"gather<1,2,1,4>", (const void*)gather_gemm_kernel<1, 2, 1, 4>}, {"thin_gather", (const void*)thin_gather_kernel},
+        {"gather<2,2,2,2,S>", (const void*)gather_gemm_kernel<2, 2, 2, 2, true>}, {"gather<2,2,1,4,S>", (const void*)gather_gemm_kernel<2, 2, 1, 4, true>},
+        {"gather<1,2,1,4,S>", (const void*)gather_gemm_kernel<1, 2, 1, 4, true>}, {"gather<2,2,2,2,T>", (const void*)gather_gemm_kernel<2, 2, 2, 2, false>},
+        {"thin_gather", (const void*)thin_gather_kernel},
         {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2>},
         {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4>},
         {"wgrad<1,2,1,4>", (const void*)wgrad_gemm_kernel<1, 2, 1, 4>}, {"wgrad<1,1,1,4>", (const void*)wgrad_gemm_kernel<1, 1, 1, 4>},
@@ -1039,6 +1124,12 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
     }
     return (int)off;
 }
+
+#ifdef DCV_STAMP
+int dcv_debug_read_stamps(unsigned long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 24 * (size_t)nblocks, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 const char* dcv_last_error(void) { return g_err; }
 int dcv_version(void) { return 1; }
