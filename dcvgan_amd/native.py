@@ -131,6 +131,8 @@ def ptr(t: Optional[torch.Tensor]):
 
 
 def stream_ptr():
+    if not torch.cuda.is_available():
+        raise NativeError("no HIP device: the DCVGAN kernels run on the GPU only (there is no CPU fallback)")
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

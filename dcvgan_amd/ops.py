@@ -343,11 +343,13 @@ def gru_sequence(e, h0, w_ih, w_hh, b_ih, b_hh):
 # --------------------------------------------------------------------------- #
 def normal(shape, device, seed: int, offset: int) -> torch.Tensor:
     out = _empty(tuple(shape), device)
+    N._require(out, "normal() output")
     check(lib().dcv_normal_fill(ptr(out), out.numel(), int(seed), int(offset), stream_ptr()), "dcv_normal_fill")
     return out
 
 
 def dropout2d_mask(n: int, c: int, p: float, device, seed: int, offset: int) -> torch.Tensor:
     out = _empty((n, c, 1, 1), device)
+    N._require(out, "dropout2d_mask() output")
     check(lib().dcv_dropout_mask(ptr(out), out.numel(), float(p), int(seed), int(offset), stream_ptr()), "dcv_dropout_mask")
     return out

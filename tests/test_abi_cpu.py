@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/dcvgan_hip.h
+declares (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from dcvgan_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return native.lib()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dcvgan_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    from dcvgan_amd import native
+    names = declared_symbols()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(native.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in dcvgan_hip.h but not exported"
+    assert set(names) == set(native.EXPORTS), (set(names) ^ set(native.EXPORTS))
+
+
+def test_version_and_error_channel(lib):
+    assert lib.dcv_version() >= 1
+    assert isinstance(lib.dcv_last_error(), bytes)
+    assert lib.dcv_launch_count() == 0  # nothing launched on a CPU-only box
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    """Geometry checks run on the host before any launch: bad shapes fail with DCV_EINVAL."""
+    from dcvgan_amd.native import ConvGeom, Dims5
+    g = ConvGeom(1, 4, 4, 1, 2, 2, 0, 1, 1, 0, 3, 8)
+    x = Dims5(2, 3, 1, 16, 16, 768, 256, 0, 16, 1)
+    y_bad = Dims5(2, 8, 1, 9, 8, 576, 72, 0, 8, 1)
+    y_ok = Dims5(2, 8, 1, 8, 8, 512, 64, 0, 8, 1)
+    assert lib.dcv_conv_workspace_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_bad), 0) == 0
+    assert b"extent" in lib.dcv_last_error()
+    for which in (0, 1, 2):
+        assert lib.dcv_conv_workspace_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), which) > 0
+    assert lib.dcv_conv_forward(ctypes.byref(g), None, ctypes.byref(x), None, None, ctypes.byref(y_ok), 0, 0.0, None, 0, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback(lib):
+    import torch
+    from dcvgan_amd import native, ops
+    x = torch.zeros(1, 3, 8, 8)
+    w = torch.zeros(4, 3, 4, 4)
+    with pytest.raises(native.NativeError):
+        ops.conv(x, w, ops.conv_geom(w, (2, 2), (1, 1), False))
+
+
+def test_no_product_import_of_oracle():
+    """Nothing under dcvgan_amd/ may import the oracle (it is test infrastructure)."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "dcvgan_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), os.path.join(dp, f)
