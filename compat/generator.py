@@ -1,0 +1,6 @@
+"""Drop-in alias: put this directory on sys.path and `import generator` resolves to the HIP-backed
+implementation with the reference's names (src/generator.py).  See INTEGRATION.md."""
+from dcvgan_amd.generator import *  # noqa: F401,F403
+from dcvgan_amd import generator as _impl
+
+globals().update({k: v for k, v in vars(_impl).items() if not k.startswith("__")})
