@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-minimal", action="store_true", help="skip the secondary run with the dead D-phase generator backward elided")
     return ap.parse_args()
 
 
@@ -67,8 +68,21 @@ def dominant_kernel_probe(models, cfg, dev):
             "achieved": flops / ms / 1e9, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
 
 
+def host_threads():
+    """CPUs this process may really use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(cfg, batch, steps):
     from dcvgan_amd import trainer
+    torch.set_num_threads(host_threads())
     from oracle import dcvgan_oracle as O
     c = cfg.scaled(batchsize=batch)
     torch.manual_seed(c.seed)
@@ -146,6 +160,27 @@ def main():
         dt = t.item()
     launches = native.launch_count() - n0
     losses = {k: float(v) for k, v in out.items()}
+
+    # secondary, clearly labelled: same parameters/updates, dead D-phase generator backward elided
+    minimal = None
+    if not a.no_minimal:
+        runner2 = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=False, elide_dead_backward=True)
+        runner2.step(xc, xg, 0)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            runner2.step(xc, xg, i % cfg.video_length)
+        sync()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = t.item()
+        f_min = FLOPS_PER_VIDEO_STEP[a.config][1]
+        minimal = {"note": "NOT the headline: D-phase fakes built without a tape (StepRunner(elide_dead_backward=True)); identical "
+                           "parameter updates, FLOPs = BASELINE.md 'minimal' column",
+                   "value": B * world / (dt2 / a.steps), "unit": "videos/s", "ms_per_step": dt2 / a.steps * 1e3,
+                   "flops_per_video_step": f_min, "frac": f_min * (B / (dt2 / a.steps)) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     assert all(x == x and abs(x) < 1e4 for x in losses.values()), losses
 
     if rank == 0:
@@ -154,6 +189,14 @@ def main():
         f_step = FLOPS_PER_VIDEO_STEP[a.config][0]
         tfl = f_step * (B / (dt / a.steps)) / 1e12  # per GPU
         probe = dominant_kernel_probe(models, cfg, dev)
+        traffic = None
+        try:  # HBM bytes per step from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE are in KB)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            kb = sum(v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in pm.values())
+            traffic = {"hbm_gb_per_step": kb * 1024 / 2 / 1e9, "algorithmic_gb_per_step": 1.06 * B, "source": "profiles/r01_pmc_summary.json "
+                       "(2 steps; FETCH_SIZE raw — dword gathers are uncalibrated on gfx950, wide streams read 1/2)"}
+        except Exception:
+            pass
         line = {
             "metric": "videos/sec per G+D step, 16x64x64 RGB+depth", "value": vps, "unit": "videos/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
@@ -162,9 +205,10 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "clip": "16x64x64 RGB + geometry",
                        "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup)},
             "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "flops_per_video_step": f_step, "dominant_kernel": probe},
             "cpu_baseline": cpu,
+            "minimal_schedule": minimal,
             "losses_last_step": losses,
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
         }

@@ -55,10 +55,17 @@ def build_optimizers(cfg: StepConfig, models, data_parallel: bool = False):
 
 
 class StepRunner:
-    def __init__(self, cfg: StepConfig, models, optimizers, loss, sync_losses: bool = False):
+    """`elide_dead_backward=True` builds the D-phase fakes without a tape (they are detached): the
+    reference backpropagates `loss_dis` through cgen/ggen too (trainer.py:304-319, fakes not detached)
+    and then throws those gradients away with `zero_grad()` at :340-341, so parameters, buffers and
+    losses are identical either way; only ~23 % of the step's FLOPs disappear (BASELINE.md §4,
+    "minimal" column).  Default False = the reference's as-written schedule."""
+
+    def __init__(self, cfg: StepConfig, models, optimizers, loss, sync_losses: bool = False, elide_dead_backward: bool = False):
         self.cfg, self.models, self.opt, self.loss = cfg, models, optimizers, loss
         self.iteration = 0
         self.sync_losses = sync_losses
+        self.elide_dead_backward = elide_dead_backward
         if cfg.start_in_eval:  # trainer.py:266-267: log_samples/evaluate leave the generators in eval()
             models["ggen"].eval(); models["cgen"].eval()
 
@@ -72,8 +79,9 @@ class StepRunner:
         for d in (idis, vdis, gdis):
             d.zero_grad()
         y_real = (idis(xg_real[:, :, t_rand], xc_real[:, :, t_rand]), vdis(xg_real, xc_real), gdis(xg_real, xc_real))
-        xg_fake = ggen.sample_videos(c.batchsize)
-        xc_fake = cgen.forward_videos(xg_fake)
+        with torch.set_grad_enabled(not self.elide_dead_backward):
+            xg_fake = ggen.sample_videos(c.batchsize)
+            xc_fake = cgen.forward_videos(xg_fake)
         y_fake = (idis(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]), vdis(xg_fake, xc_fake), gdis(xg_fake, xc_fake))
         loss_idis = self.loss.compute_dis_loss(y_real[0], y_fake[0])
         loss_vdis = self.loss.compute_dis_loss(y_real[1], y_fake[1])

@@ -161,8 +161,9 @@ def test_discriminators(dev, fixture):
                 assert np.allclose(v.cpu().numpy(), fx[key], rtol=1e-4, atol=1e-6), key
 
 
+@pytest.mark.parametrize("elide", [False, True], ids=["as_written", "dead_backward_elided"])
 @pytest.mark.parametrize("fixture", ["step_depth_adv_g1.npz", "step_depth_adv_g1_evalstart.npz", "step_flow_hinge_g2.npz"])
-def test_training_step(dev, fixture):
+def test_training_step(dev, fixture, elide):
     """3 iterations of trainer.py:279-363: losses + post-step parameter checksums vs the reference."""
     from dcvgan_amd import trainer
     fx = G.load(fixture)
@@ -181,7 +182,8 @@ def test_training_step(dev, fixture):
     # HIP run with the same draws
     models = hip_models(fx, cfg, dev)
     r = share_rng(models, so.rng.log)
-    runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
+    runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True,
+                                elide_dead_backward=elide)
     xc_d, xg_d = xc_real.to(dev), xg_real.to(dev)
     for it in range(1, iters + 1):
         got = runner.step(xc_d, xg_d, int(fx["meta/t_rands"][it - 1]))

@@ -17,6 +17,19 @@ for _ in range(2):
     rc = L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
     assert rc == 0
 torch.cuda.synchronize()
+def run(lib_):
+    lib_.dcv_conv_workspace_bytes.restype = C.c_size_t
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
+    e0.record()
+    for _ in range(5):
+        lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / 5
+Lp = C.CDLL("dcvgan_amd/libdcvgan_hip.so")
+for rep in range(2):
+    print("wall ms/op: stamp build %.3f   shipped build %.3f" % (run(L), run(Lp)))
 buf = np.zeros((4096, 4, 6), dtype=np.uint64)
 L.dcv_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), 4096)
 b = buf.astype(np.float64)
