@@ -23,6 +23,7 @@
 // (KEntry) carry all index arithmetic so one kernel serves every geometry.
 #include "dcv_common.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -313,6 +314,189 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
     }
 
     // ---- epilogue: acc[i][j][r] -> oc = .. + (r&3) + 8*(r>>2) + 4*lhi, m = .. + l31 ----
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 32 + l31;
+        if (m >= a.M) continue;
+        const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+        uint32_t r0 = (uint32_t)m - n * a.div_sp.div;
+        const uint32_t od = fdiv(r0, a.div_hw);
+        r0 -= od * a.div_hw.div;
+        const uint32_t oh = fdiv(r0, a.div_w);
+        const uint32_t ow = r0 - oh * a.div_w.div;
+        float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+#pragma unroll
+        for (int i = 0; i < TOC; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (oc < a.OC) {
+                    float v = acc[i][j][r];
+                    float* p = yb + (int64_t)oc * a.y_sc;
+                    if (a.accumulate) v += *p;
+                    *p = apply_act(v, a.act, a.slope);
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// gather GEMM, LDS-DMA form (structured K walk only).  Same tiling and epilogue as
+// gather_gemm_kernel, but both operand tiles go global -> LDS directly
+// (buffer_load ... lds): the X tile row k / 64 consecutive positions of a wave is exactly one
+// lane-linear 256-B DMA write, the packed W tile is lane-linear in float4s.  No staging
+// registers, no LDS-store phase, one barrier per K step; padding still arrives as zeros through
+// the out-of-range voffset.  Per step: wait own DMAs + barrier, issue next tile's DMAs into the
+// other buffer, 32 MFMAs per wave on this one.
+// --------------------------------------------------------------------------- //
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int TOC, int TM, int WOC, int WM>
+__global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgs a) {
+    constexpr int BN = 32 * TOC * WOC;
+    constexpr int BM = 32 * TM * WM;
+    constexpr int XPT = 16 * BM / 256;
+    constexpr int WF4 = 16 * BN / 4;
+    constexpr int WPT = (WF4 + 255) / 256;
+    static_assert(WOC * WM == 4, "4 waves");
+    // ONE LDS array: [2][16][BM] X tiles then [2][16][BN] W tiles
+    __shared__ __attribute__((aligned(16))) float smem[2 * 16 * BM + 2 * 16 * BN];
+    float* const Xs = smem;
+    float* const Ws = smem + 2 * 16 * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int woc = wave / WM, wm = wave % WM;
+    const int tiles_oc = a.OCp / BN;
+    const int oc_t = blockIdx.x % tiles_oc;
+    const int m_t = blockIdx.x / tiles_oc;
+    const int oc0 = oc_t * BN;
+    const int m0 = m_t * BM;
+
+    const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n0 * a.x_sn), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wp), 0, 0x80000000u, 0x00020000);
+
+    const int lm = tid % BM;
+    const int ksub = __builtin_amdgcn_readfirstlane(tid / BM);
+    const int lm_wave = __builtin_amdgcn_readfirstlane(lm - lane);   // first position column of this wave
+    int xbase4 = 0;
+    uint32_t vmask = 0;
+    {
+        const int m = m0 + lm;
+        if (m < a.M) {
+            const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+            uint32_t r = (uint32_t)m - n * a.div_sp.div;
+            const uint32_t od = fdiv(r, a.div_hw);
+            r -= od * a.div_hw.div;
+            const uint32_t oh = fdiv(r, a.div_w);
+            const uint32_t ow = r - oh * a.div_w.div;
+            vmask = dim_mask(a.td, (int)od, 0) | dim_mask(a.th, (int)oh, 8) | dim_mask(a.tw, (int)ow, 16);
+            xbase4 = 4 * ((int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd +
+                          ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw);
+        }
+    }
+    uint32_t vloc[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int r = ksub * XPT + i;
+        const uint32_t sel = a.s_sel[r];
+        vloc[i] = ((vmask & sel) == sel) ? (uint32_t)(xbase4 + a.s_local[r]) : 0x80000000u;
+    }
+    // W tile: float4 index f = tid + 256 j -> row f / (BN/4), column 4 (f % (BN/4)); LDS offset = 4 f floats
+    uint32_t wvo[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int f = tid + 256 * j;
+        const int row = f / (BN / 4), c4 = f % (BN / 4);
+        wvo[j] = (uint32_t)(4 * (row * a.OCp + oc0 + c4 * 4));
+    }
+    const int wstep4 = 16 * a.OCp * 4;
+
+    // The host pass type-checks builtins without gfx950 target features and rejects the 16-byte
+    // LDS-DMA size, which silently drops the kernel's host stub: device pass only.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DCV_ISSUE_TILE(IT, BUF)                                                                                         \
+    {                                                                                                                   \
+        const int it_ = (IT);                                                                                           \
+        const int soff_ = (it_ >> a.s_log2p) * a.s_stepA + (it_ & ((1 << a.s_log2p) - 1)) * a.s_stepD;                  \
+        float* xb_ = Xs + (BUF) * 16 * BM + lm_wave;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(xb_ + (ksub * XPT + i) * BM), 4, vloc[i], soff_, 0, 0); \
+        float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
+        _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                 \
+            if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4) /* wave-uniform: whole waves only */                       \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], it_ * wstep4, 0, 0); \
+    }
+#else
+#define DCV_ISSUE_TILE(IT, BUF) { (void)wstep4; (void)wvo; (void)vloc; (void)lm_wave; }
+#endif
+
+    f32x16 acc[TOC][TM];
+#pragma unroll
+    for (int i = 0; i < TOC; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int it0 = a.slab ? blockIdx.y * a.kper : 0;
+    const int it1 = a.slab ? min(a.KIT, it0 + a.kper) : a.KIT;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    DCV_ISSUE_TILE(it0, 0)
+    for (int it = it0; it < it1; ++it) {
+        const int buf = (it - it0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile `it` have landed
+        __syncthreads();                                   // ... everyone's have; and all reads of buf^1 are done
+        if (it + 1 < it1) DCV_ISSUE_TILE(it + 1, buf ^ 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const float* xt = Xs + buf * 16 * BM;
+        const float* wt = Ws + buf * 16 * BN;
+        __builtin_amdgcn_s_setprio(2);
+        float af[2][TOC], bf[2][TM];
+#pragma unroll
+        for (int i = 0; i < TOC; ++i) af[0][i] = wt[lhi * BN + (woc * TOC + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) bf[0][j] = xt[lhi * BM + (wm * TM + j) * 32 + l31];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 8) {
+                const int k = 2 * (ks + 1) + lhi;
+#pragma unroll
+                for (int i = 0; i < TOC; ++i) af[nxt][i] = wt[k * BN + (woc * TOC + i) * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) bf[nxt][j] = xt[k * BM + (wm * TM + j) * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (a.slab) {
+        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    sl[(int64_t)oc * a.Mp + m0 + (wm * TM + j) * 32 + l31] = acc[i][j][r];
+                }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 32 + l31;
@@ -690,7 +874,9 @@ static TileCfg pick_gather_tile(int OC) {
 
 template <int TOC, int TM, int WOC, int WM>
 static void launch_gather(const GatherArgs& a, dim3 grid, hipStream_t s) {
-    if (a.structured) hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, a);
+    static const bool use_dma = getenv("DCV_NO_LDS_DMA") == nullptr;
+    if (a.structured && use_dma) hipLaunchKernelGGL((gather_gemm_dma_kernel<TOC, TM, WOC, WM>), grid, dim3(256), 0, s, a);
+    else if (a.structured) hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, false>), grid, dim3(256), 0, s, a);
 }
 
@@ -1104,6 +1290,8 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
     const Item items[] = {
         {"gather<2,2,2,2,S>", (const void*)gather_gemm_kernel<2, 2, 2, 2, true>}, {"gather<2,2,1,4,S>", (const void*)gather_gemm_kernel<2, 2, 1, 4, true>},
         {"gather<1,2,1,4,S>", (const void*)gather_gemm_kernel<1, 2, 1, 4, true>}, {"gather<2,2,2,2,T>", (const void*)gather_gemm_kernel<2, 2, 2, 2, false>},
+        {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4>},
+        {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4>},
         {"thin_gather", (const void*)thin_gather_kernel},
         {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2>},
         {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4>},
