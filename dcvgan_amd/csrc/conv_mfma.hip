@@ -622,6 +622,102 @@ __global__ __launch_bounds__(256) void thin_gather_kernel(const GatherArgs a) {
         }
 }
 
+// Structured thin gather: all T taps of a channel are walked with per-tap voffsets fixed for the
+// whole loop (padding folded in), the channel advances by a scalar soffset, the weights of one
+// channel (T x 4 floats, K-major packed) are scalar loads.  Per (channel, tap): 1 buffer load +
+// NOC FMAs, no index arithmetic.  64 positions per block; the 4 waves split the channels.
+template <int T, int NOC>
+__global__ __launch_bounds__(256) void thin_struct_kernel(const GatherArgs a, int RC, int rc_per_split) {
+    __shared__ float red[3][4][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 64;
+    const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n0 * a.x_sn), 0, 0x80000000u, 0x00020000);
+    const int m = m0 + lane;
+    int xbase4 = 0;
+    uint32_t vmask = 0;
+    uint32_t n = 0, od = 0, oh = 0, ow = 0;
+    if (m < a.M) {
+        n = fdiv((uint32_t)m, a.div_sp);
+        uint32_t r = (uint32_t)m - n * a.div_sp.div;
+        od = fdiv(r, a.div_hw);
+        r -= od * a.div_hw.div;
+        oh = fdiv(r, a.div_w);
+        ow = r - oh * a.div_w.div;
+        vmask = dim_mask(a.td, (int)od, 0) | dim_mask(a.th, (int)oh, 8) | dim_mask(a.tw, (int)ow, 16);
+        xbase4 = 4 * ((int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd +
+                      ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw);
+    }
+    uint32_t vloc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const uint32_t sel = a.s_sel[t];
+        vloc[t] = ((vmask & sel) == sel) ? (uint32_t)(xbase4 + a.s_local[t]) : 0x80000000u;
+    }
+    // channels of this block's split, then of this wave
+    const int cb0 = a.slab ? blockIdx.y * rc_per_split : 0;
+    const int cb1 = a.slab ? min(RC, cb0 + rc_per_split) : RC;
+    const int cper = (cb1 - cb0 + 3) / 4;
+    const int c0 = cb0 + wave * cper, c1 = min(cb1, c0 + cper);
+    float acc[NOC];
+#pragma unroll
+    for (int c = 0; c < NOC; ++c) acc[c] = 0.f;
+    for (int rc = c0; rc < c1; ++rc) {
+        const int soff = rc * a.s_stepA;
+        const float4* __restrict__ wrow = reinterpret_cast<const float4*>(a.wp) + (int64_t)rc * T;   // wave-uniform
+        float xv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) xv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vloc[t], soff, 0));
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float4 w = wrow[t];
+            acc[0] += w.x * xv[t];
+            if (NOC > 1) acc[1] += w.y * xv[t];
+            if (NOC > 2) acc[2] += w.z * xv[t];
+            if (NOC > 3) acc[3] += w.w * xv[t];
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) red[wave - 1][c][lane] = acc[c];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) acc[c] += red[w][c][lane];
+    if (a.slab) {
+        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sl[(int64_t)c * a.Mp + m] = c < NOC ? acc[c < NOC ? c : 0] : 0.f;
+        return;
+    }
+    if (m >= a.M) return;
+    float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+#pragma unroll
+    for (int c = 0; c < NOC; ++c)
+        if (c < a.OC) {
+            float v = acc[c];
+            float* q = yb + (int64_t)c * a.y_sc;
+            if (a.accumulate) v += *q;
+            *q = apply_act(v, a.act, a.slope);
+        }
+}
+
+template <int T>
+static bool launch_thin_struct(const GatherArgs& a, int OC, int RC, int rc_per_split, dim3 grid, hipStream_t s) {
+    switch (OC) {
+        case 1: hipLaunchKernelGGL((thin_struct_kernel<T, 1>), grid, dim3(256), 0, s, a, RC, rc_per_split); return true;
+        case 2: hipLaunchKernelGGL((thin_struct_kernel<T, 2>), grid, dim3(256), 0, s, a, RC, rc_per_split); return true;
+        case 3: hipLaunchKernelGGL((thin_struct_kernel<T, 3>), grid, dim3(256), 0, s, a, RC, rc_per_split); return true;
+        case 4: hipLaunchKernelGGL((thin_struct_kernel<T, 4>), grid, dim3(256), 0, s, a, RC, rc_per_split); return true;
+    }
+    return false;
+}
+
 // Wp[k][oc] = w[oc * ws_o + ktab[k].w_off]   (zero for padding rows / channels)
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, const KEntry* __restrict__ ktab,
                                     int K16, int OC, int OCp, int64_t ws_o) {
@@ -1017,12 +1113,26 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.slab = slab;
         a.kper = kper;
         a.Mp = Mp;
+        bool thin_struct = false;
+        if (tc.bn == 4 && (T == 4 || T == 9 || T == 16) && xd.sc * 4 < (1ll << 30) && (KS2 == 1 || (kper * 16) % T == 0)) {
+            // K order is (rc, ud, uh, uw): tap t of every channel has the same relative offset
+            thin_struct = true;
+            const int nh = c.taps[1].n, nw = c.taps[2].n, THW = nh * nw;
+            a.s_stepA = (int32_t)(xd.sc * 4);
+            for (int t = 0; t < T; ++t) {
+                const int ud = t / THW, uh = (t / nw) % nh, uw = t % nw;
+                a.s_local[t] = (int32_t)(4 * (c.taps[0].delta[ud] * xd.sd + c.taps[1].delta[uh] * xd.sh + c.taps[2].delta[uw] * xd.sw));
+                a.s_sel[t] = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
+            }
+        }
         // ---- structured K walk? (K order is (rc, ud, uh, uw), 16 rows per step) ----
         {
             const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n, THW = nh * nw;
             const int64_t sc4 = xd.sc * 4;
             a.structured = 0;
-            if (16 % T == 0 && RC % (16 / T) == 0 && sc4 * (16 / T) < (1ll << 30)) {
+            if (tc.bn == 4) {
+                // thin kernels have their own (per-tap) structured walk, set up above
+            } else if (16 % T == 0 && RC % (16 / T) == 0 && sc4 * (16 / T) < (1ll << 30)) {
                 // every step covers 16/T whole channels with all T taps
                 a.structured = 1;
                 a.s_log2p = 0;
@@ -1048,7 +1158,12 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
         }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
-        if (tc.bn == 4) hipLaunchKernelGGL(thin_gather_kernel, grid, dim3(256), 0, stream, a);
+        if (tc.bn == 4 && thin_struct) {
+            const int rcps = KS2 > 1 ? kper * 16 / T : RC;   // whole channels per K split
+            if (T == 4) launch_thin_struct<4>(a, OC, RC, rcps, grid, stream);
+            else if (T == 9) launch_thin_struct<9>(a, OC, RC, rcps, grid, stream);
+            else launch_thin_struct<16>(a, OC, RC, rcps, grid, stream);
+        } else if (tc.bn == 4) hipLaunchKernelGGL(thin_gather_kernel, grid, dim3(256), 0, stream, a);
         else if (tc.bn == 128) launch_gather<2, 2, 2, 2>(a, grid, stream);
         else if (tc.bn == 64) launch_gather<2, 2, 1, 4>(a, grid, stream);
         else launch_gather<1, 2, 1, 4>(a, grid, stream);
@@ -1155,13 +1270,15 @@ struct WgradTile {
     int bd, bj;
 };
 static WgradTile pick_wgrad_tile(int DC, int J) {
+    if (J <= 32) return WgradTile{128, 32};   // stems: few gathered channels x taps
     if (DC > 64) return (J > 64) ? WgradTile{128, 128} : WgradTile{128, 64};
     if (DC > 32) return (J > 128) ? WgradTile{64, 256} : WgradTile{64, 128};
     return (J > 128) ? WgradTile{32, 256} : WgradTile{32, 128};
 }
 
 static int wgrad_splits(int64_t M, int tiles) {
-    // aim for ~1024 blocks, at least 8 reduction steps (256 positions) per block
+    // aim for ~1024 blocks, at least 8 reduction steps (256 positions) per block (measured: fewer,
+    // longer blocks lose more MFMA time than the slab reduce saves)
     int64_t want = (1024 + tiles - 1) / tiles;
     int64_t maxs = (M + 255) / 256;
     int64_t s = want < maxs ? want : maxs;
@@ -1264,7 +1381,8 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     a.d_sn = dd.sn; a.g_sn = gd.sn;
     a.d_sc4 = (int32_t)(dd.sc * 4); a.d_sd = (int32_t)dd.sd; a.d_sh = (int32_t)dd.sh; a.d_sw = (int32_t)dd.sw;
     a.g_sd = (int32_t)gd.sd; a.g_sh = (int32_t)gd.sh; a.g_sw = (int32_t)gd.sw;
-    if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
+    if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
+    else if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 64) launch_wgrad<2, 1, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 64 && tc.bj == 256) launch_wgrad<2, 2, 1, 4>(a, tiles, S2, stream);
     else if (tc.bd == 64 && tc.bj == 128) launch_wgrad<2, 1, 1, 4>(a, tiles, S2, stream);
