@@ -59,10 +59,14 @@ class _PairDiscriminator(nn.Module):
 
     def forward(self, xg, xc):
         rng = self._source()
-        hg = layers.run(self.conv_g, xg, rng)   # draw order: geometry stem first (discriminator.py:122-123)
-        hc = layers.run(self.conv_c, xc, rng)
-        h = ops.cat_channels(hc, hg)            # colour first (discriminator.py:124,228)
-        return layers.run(self.main, h, rng).squeeze()
+        # cat([hc, hg]) (colour first, discriminator.py:124,228): both stems write into one buffer
+        conv = self.conv_g[-2]
+        half = conv.out_channels
+        sp = ops._out_shape(layers.geom_of(conv), xg)[2:]
+        cat = ops.ConcatBuffer(xg.shape[0], half, half, sp, xg.device)
+        hg = layers.run(self.conv_g, xg, rng, out=cat.second)   # draw order: geometry stem first (discriminator.py:122-123)
+        hc = layers.run(self.conv_c, xc, rng, out=cat.first)
+        return layers.run(self.main, cat.join(hc, hg), rng).squeeze()
 
 
 class ImageDiscriminator(_PairDiscriminator):

@@ -123,8 +123,8 @@ class Outconv(nn.Module):
         self.main = nn.Sequential(_convT(in_ch, out_ch, 3, 1, 1), nn.Tanh())
 
 
-def _block_forward(self, x, rng=None):
-    return layers.run(self.main, x, rng if rng is not None else default_rng())
+def _block_forward(self, x, rng=None, out=None):
+    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out)
 
 
 for _cls in (Inconv, DownBlock, UpBlock, Outconv):
@@ -161,15 +161,25 @@ class ColorVideoGenerator(nn.Module):
         if self.geometric_info == "segmentation":  # one-hot -> {-1, +1} maps (generator.py:378-385); SURVEY §8(f).4
             idx = torch.argmax(x, 1, keepdim=True)
             x = torch.full_like(x, -1.0).scatter_(1, idx, 1.0)
-        skips = [self.inconv(x, rng)]
-        for blk in self.down_blocks:
-            skips.append(blk(skips[-1], rng))
-        h = ops.cat_channels(skips[-1], z)
+        # Every torch.cat of the reference (generator.py:393-400) joins an up-path tensor with a skip:
+        # both producers write straight into the two channel slices of one buffer, so no copy is made.
+        nb = x.shape[0]
+        widths = [self.inconv.main[0].out_channels] + [b.main[0].out_channels for b in self.down_blocks]   # skip channels
+        ups = [b.main[0].out_channels for b in self.up_blocks]
+        size = [x.shape[2] >> k for k in range(7)]                       # 64, 32, ..., 1
+        # bufs[k] (k = 0..5): cat([up-path tensor at resolution size[k], skips[k]]); bufs[6]: cat([skips[6], z])
+        bufs = [ops.ConcatBuffer(nb, ups[5 - k], widths[k], (size[k], size[k]), x.device) for k in range(6)]
+        bufs.append(ops.ConcatBuffer(nb, widths[6], self.dim_z, (size[6], size[6]), x.device))
+        skips = [self.inconv(x, rng, out=bufs[0].second)]
+        for k, blk in enumerate(self.down_blocks):
+            dst = bufs[k + 1].second if k + 1 < 6 else bufs[6].first
+            skips.append(blk(skips[-1], rng, out=dst))
+        zc = ops.copy_into(z, bufs[6].second)
+        h = bufs[6].join(skips[6], zc)
         for i, blk in enumerate(self.up_blocks):
-            if i:
-                h = ops.cat_channels(h, skips[-i - 1])
-            h = blk(h, rng)
-        return self.outconv(ops.cat_channels(h, skips[0]), rng)
+            h = blk(h, rng, out=bufs[5 - i].first)
+            h = bufs[5 - i].join(h, skips[5 - i])
+        return self.outconv(h, rng)
 
     def forward_videos(self, xs: torch.Tensor) -> torch.Tensor:
         B, Cg, T, H, W = xs.shape

@@ -43,7 +43,7 @@ def geom_of(conv) -> "ops.ConvGeom":
     return ops.conv_geom(conv.weight, conv.stride, conv.padding, isinstance(conv, nn.ConvTranspose2d))
 
 
-def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None):
+def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None):
     training = bn.training
     mask = None
     if dropout is not None and dropout.training:
@@ -51,10 +51,12 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
-                      bn.momentum if bn.momentum is not None else 0.1, bn.eps)
+                      bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out)
 
 
-def run(seq: nn.Sequential, x: torch.Tensor, rng) -> torch.Tensor:
+def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
+    """`out`: destination view for the sequence's LAST fused op (a concat-buffer slice), when that
+    op is a conv(+act) or a BatchNorm group."""
     layers = list(seq)
     i, n = 0, len(layers)
     while i < n:
@@ -63,10 +65,10 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng) -> torch.Tensor:
         if isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None
             if fused is not None:
-                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1])
+                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None)
                 i += 2
             else:
-                x = ops.conv(x, layer.weight, geom_of(layer))
+                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None)
                 i += 1
         elif isinstance(layer, _BNS):
             j = i + 1
@@ -77,7 +79,7 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng) -> torch.Tensor:
             fused = _act_of(layers[j]) if j < n else None
             if fused is not None:
                 j += 1
-            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop)
+            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop, out=out if j >= n else None)
             i = j
         elif _act_of(layer) is not None:
             code, slope = _act_of(layer)

@@ -70,14 +70,33 @@ def _out_shape(g: ConvGeom, x: torch.Tensor):
     return (x.shape[0], g.cout, o[0], o[1], o[2])
 
 
+class _Out:
+    """Wrapper that keeps a destination view out of autograd's sight (it is plain memory to write
+    into, e.g. a channel slice of a concat buffer)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def _dest(out, shape, device):
+    if out is None:
+        return _empty(shape, device)
+    t = out.t
+    if tuple(t.shape) != tuple(shape):
+        raise N.NativeError(f"out= has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    N._require(t, "out= destination")
+    return t.detach()  # fresh tensor object sharing the memory; becomes the op's output
+
+
 class _Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
         w = w.contiguous()
-        y = _empty(_out_shape(g, x), x.device)
+        y = _dest(out, _out_shape(g, x), x.device)
         xd, yd = dims5(x), dims5(y)
         L = lib()
         need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0)
@@ -97,8 +116,8 @@ class _Conv(Function):
         dy = _dense(dy)
         if ctx.act != ACT_NONE:
             dz = _empty(y.shape, y.device)
-            dyd, yd = dims5(dy), dims5(y)
-            check(L.dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dz), C.byref(yd), ctx.act, ctx.slope, stream_ptr()), "dcv_act_backward")
+            dyd, yd, dzd = dims5(dy), dims5(y), dims5(dz)   # y may be a strided concat-buffer slice; dz is dense
+            check(L.dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dz), C.byref(dzd), ctx.act, ctx.slope, stream_ptr()), "dcv_act_backward")
             dy = dz
         xd, dyd = dims5(x), dims5(dy)
         dx = dw = None
@@ -113,12 +132,13 @@ class _Conv(Function):
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0):
-    """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries."""
-    return _Conv.apply(x, w, g, act, float(slope))
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None):
+    """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries.
+    `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into."""
+    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out))
 
 
 # --------------------------------------------------------------------------- #
@@ -126,11 +146,11 @@ def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0):
 # --------------------------------------------------------------------------- #
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float, out=None):
         N._require(x, "bn input")
         L = lib()
         Cn = x.shape[1]
-        y = _empty(x.shape, x.device)
+        y = _dest(out, x.shape, x.device)
         stats = _empty((2, Cn), x.device)
         xd, yd = dims5(x), dims5(y)
         wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
@@ -155,13 +175,14 @@ class _BnAct(Function):
         check(L.dcv_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta),
                                     ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()),
               "dcv_bn_act_backward")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0,
-           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5):
+           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None):
     """y = act(mask * batch_norm(x)); running stats are updated in place when training."""
-    return _BnAct.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope))
+    return _BnAct.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope),
+                        None if out is None else _Out(out))
 
 
 # --------------------------------------------------------------------------- #
@@ -184,8 +205,8 @@ class _Act(Function):
         act, slope = ctx.cfg
         dy = _dense(dy)
         dx = _empty(y.shape, y.device)
-        dyd, yd = dims5(dy), dims5(y)
-        check(lib().dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dx), C.byref(yd), act, slope, stream_ptr()), "dcv_act_backward")
+        dyd, yd, dxd = dims5(dy), dims5(y), dims5(dx)
+        check(lib().dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dx), C.byref(dxd), act, slope, stream_ptr()), "dcv_act_backward")
         return dx, None, None
 
 
@@ -244,6 +265,53 @@ class _CatChannels(Function):
 def cat_channels(a, b):
     """torch.cat([a, b], 1) as two strided copies into channel slices."""
     return _CatChannels.apply(a, b)
+
+
+class _CopyInto(Function):
+    @staticmethod
+    def forward(ctx, x, holder):
+        dst = holder.t
+        _axpby(x, 1.0, None, 0.0, dst)
+        return dst.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def copy_into(x, dst):
+    """Strided copy of x into the view dst (a concat-buffer slice); gradient passes through."""
+    return _CopyInto.apply(x, _Out(dst))
+
+
+class _JoinSlices(Function):
+    """cat([a, b], 1) when a and b were WRITTEN INTO adjacent channel slices of `buf` by their
+    producers (conv / bn_act with out=): nothing to copy, the result is `buf` itself."""
+
+    @staticmethod
+    def forward(ctx, a, b, holder):
+        buf = holder.t
+        ca, cb = a.shape[1], b.shape[1]
+        if buf.shape[1] != ca + cb or a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf[:, ca:].data_ptr() \
+                or a.stride() != buf.stride() or b.stride() != buf.stride():
+            raise N.NativeError("join_slices: operands are not the two channel slices of the buffer")
+        ctx.ca = ca
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[:, :ctx.ca], dy[:, ctx.ca:], None
+
+
+class ConcatBuffer:
+    """A (N, Ca+Cb, ...) buffer whose two channel slices are handed to the producers as out= views."""
+
+    def __init__(self, n, ca, cb, spatial, device):
+        self.buf = _empty((n, ca + cb) + tuple(spatial), device)
+        self.first, self.second = self.buf[:, :ca], self.buf[:, ca:]
+
+    def join(self, a, b):
+        return _JoinSlices.apply(a, b, _Out(self.buf))
 
 
 class _TemporalDiff(Function):

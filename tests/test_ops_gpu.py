@@ -194,3 +194,31 @@ def test_gru_sequence(dev):
     assert rel(out, out_ref) < 1e-5
     for a, b in zip(got, g_ref):
         assert rel(a, b) < 1e-4
+
+
+def test_out_slices_and_copy_free_concat(dev):
+    """conv(+act) and bn_act writing straight into the two channel slices of a concat buffer, joined
+    without a copy: forward and all gradients equal torch's cat path.  (Regression: the fused-activation
+    backward once described its dense scratch with the strided output's strides.)"""
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 4, 16, 16, generator=g, requires_grad=True)
+    w1 = (torch.randn(6, 4, 4, 4, generator=g) * 0.2).requires_grad_(True)
+    w2 = (torch.randn(5, 4, 4, 4, generator=g) * 0.2).requires_grad_(True)
+    gam = (torch.rand(5, generator=g) + 0.5).requires_grad_(True); bet = torch.randn(5, generator=g).requires_grad_(True)
+    a_ref = F.leaky_relu(F.conv2d(x, w1, None, 2, 1), 0.2)
+    b_ref = F.relu(F.batch_norm(F.conv2d(x, w2, None, 2, 1), None, None, gam, bet, True, 0.1, 1e-5))
+    y_ref = torch.cat([a_ref, b_ref], 1)
+    cot = torch.randn(y_ref.shape, generator=g)
+    ref = torch.autograd.grad((y_ref * cot).sum(), [x, w1, w2, gam, bet])
+    xd = x.detach().to(dev).requires_grad_(True)
+    p = [t.detach().to(dev).requires_grad_(True) for t in (w1, w2, gam, bet)]
+    cb = ops.ConcatBuffer(3, 6, 5, (8, 8), dev)
+    a = ops.conv(xd, p[0], ops.conv_geom(p[0], (2, 2), (1, 1), False), ops.ACT_LEAKY, 0.2, out=cb.first)
+    h = ops.conv(xd, p[1], ops.conv_geom(p[1], (2, 2), (1, 1), False))
+    b = ops.bn_act(h, p[2], p[3], None, None, True, ops.ACT_LEAKY, 0.0, out=cb.second)
+    y = cb.join(a, b)
+    assert y.data_ptr() == cb.buf.data_ptr() and rel(y, y_ref) < TOL
+    got = torch.autograd.grad((y * cot.to(dev)).sum(), [xd] + p)
+    for u, v in zip(got, ref):
+        assert rel(u, v) < TOL
