@@ -745,10 +745,18 @@ struct WgradArgs {
     int64_t d_sn, g_sn;
     int32_t d_sc4, d_sd, d_sh, d_sw;   // d_sc4: channel stride in BYTES
     int32_t g_sd, g_sh, g_sw, pad2;
+    // regular form (4x4 inner taps): row j = (gc * nd + kd) * 16 + t
+    int32_t g_sc4, g_sd4, log2nd, pad3;
+    int32_t hw_off4[16];   // byte offset of inner tap t = kh * 4 + kw
+    uint32_t hw_sel[16];   // its selection bits
 };
 
-template <int TD, int TJ, int WD, int WJ>
-__global__ __launch_bounds__(256, (TD * TJ >= 4 ? 2 : 3)) void wgrad_gemm_kernel(const WgradArgs a) {
+// REG16: 4x4 inner taps.  A thread's gathered rows j = j0 + sub + 8 i then use only the two inner taps
+// t = sub and sub + 8 (row parity), and (channel, depth tap) = j / 16 is wave-uniform: two per-lane
+// voffsets per step (padding folded in) + precomputed scalar soffsets replace 32 per-row registers,
+// which is what lets three workgroups share a CU.
+template <int TD, int TJ, int WD, int WJ, bool REG16>
+__global__ __launch_bounds__(256, (TD * TJ >= 4 ? (REG16 ? 3 : 2) : 3)) void wgrad_gemm_kernel(const WgradArgs a) {
     constexpr int BD = 32 * TD * WD;
     constexpr int BJ = 32 * TJ * WJ;
     constexpr int DPT = BD / 8, JPT = BJ / 8;  // elements per thread per step
@@ -778,18 +786,36 @@ __global__ __launch_bounds__(256, (TD * TJ >= 4 ? 2 : 3)) void wgrad_gemm_kernel
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x80000000u, 0x00020000);
 
     // this thread's J rows (gathered channel, tap) are fixed for the whole reduction
-    int32_t goff4[JPT];
-    uint32_t gsel[JPT];
+    int32_t goff4[REG16 ? 1 : JPT];
+    uint32_t gsel[REG16 ? 1 : JPT];
+    int32_t gso[REG16 ? JPT / 2 : 1];     // REG16: scalar (channel, depth-tap) offsets of row pairs
+    uint32_t jmask = 0;                    // REG16: bit i = row j0 + sub + 8 i exists
+    int32_t tapA = 0, tapB = 0;
+    uint32_t selA = 0, selB = 0;
+    if constexpr (REG16) {
+        const int subu = sub & 7;
+        tapA = a.hw_off4[subu]; tapB = a.hw_off4[subu + 8];
+        selA = a.hw_sel[subu]; selB = a.hw_sel[subu + 8];
 #pragma unroll
-    for (int i = 0; i < JPT; ++i) {
-        const int j = j0 + sub + 8 * i;
-        if (j < a.J) {
-            const KEntry e = a.jtab[j];
-            goff4[i] = e.x_off * 4;
-            gsel[i] = e.tapsel;
-        } else {
-            goff4[i] = 0;
-            gsel[i] = 1u << 31;
+        for (int q = 0; q < JPT / 2; ++q) {
+            const int cd = j0 / 16 + q;   // (sub + 8 i) / 16 == i / 2 for sub < 8
+            gso[q] = (cd >> a.log2nd) * a.g_sc4 + (cd & ((1 << a.log2nd) - 1)) * a.g_sd4;
+        }
+#pragma unroll
+        for (int i = 0; i < JPT; ++i)
+            if (j0 + sub + 8 * i < a.J) jmask |= 1u << i;
+    } else {
+#pragma unroll
+        for (int i = 0; i < JPT; ++i) {
+            const int j = j0 + sub + 8 * i;
+            if (j < a.J) {
+                const KEntry e = a.jtab[j];
+                goff4[i] = e.x_off * 4;
+                gsel[i] = e.tapsel;
+            } else {
+                goff4[i] = 0;
+                gsel[i] = 1u << 31;
+            }
         }
     }
     const int dcb4 = (d0 + sub) * a.d_sc4;   // byte offset of this thread's first dense channel
@@ -829,10 +855,20 @@ __global__ __launch_bounds__(256, (TD * TJ >= 4 ? 2 : 3)) void wgrad_gemm_kernel
         const uint32_t vmask = mok ? (dim_mask(a.td, (int)pd, 0) | dim_mask(a.th, (int)ph, 8) | dim_mask(a.tw, (int)pw, 16)) : 0u;
         const int gbase4 = 4 * ((int)((int64_t)(n - nb) * a.g_sn) + ((int)pd * a.td.mul + a.td.base) * a.g_sd +
                                 ((int)ph * a.th.mul + a.th.base) * a.g_sh + ((int)pw * a.tw.mul + a.tw.base) * a.g_sw);
+        if constexpr (REG16) {
+            const uint32_t voA = ((vmask & selA) == selA) ? (uint32_t)(gbase4 + tapA) : 0x80000000u;
+            const uint32_t voB = ((vmask & selB) == selB) ? (uint32_t)(gbase4 + tapB) : 0x80000000u;
 #pragma unroll
-        for (int i = 0; i < JPT; ++i) {
-            const uint32_t vo = ((vmask & gsel[i]) == gsel[i]) ? (uint32_t)(gbase4 + goff4[i]) : 0x80000000u;
-            gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo, 0, 0));
+            for (int i = 0; i < JPT; ++i) {
+                const uint32_t vo = ((jmask >> i) & 1u) ? ((i & 1) ? voB : voA) : 0x80000000u;
+                gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo, gso[i / 2], 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < JPT; ++i) {
+                const uint32_t vo = ((vmask & gsel[i]) == gsel[i]) ? (uint32_t)(gbase4 + goff4[i]) : 0x80000000u;
+                gv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo, 0, 0));
+            }
         }
     };
     auto store_tile = [&]() {
@@ -1304,7 +1340,8 @@ static int wgrad_splits(int64_t M, int tiles) {
 
 template <int TD, int TJ, int WD, int WJ>
 static void launch_wgrad(const WgradArgs& a, int gx, int gy, hipStream_t s) {
-    hipLaunchKernelGGL((wgrad_gemm_kernel<TD, TJ, WD, WJ>), dim3(gx, gy), dim3(256), 0, s, a);
+    if (a.log2nd >= 0) hipLaunchKernelGGL((wgrad_gemm_kernel<TD, TJ, WD, WJ, true>), dim3(gx, gy), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_gemm_kernel<TD, TJ, WD, WJ, false>), dim3(gx, gy), dim3(256), 0, s, a);
 }
 
 // dense tensor D (dims dd, channels DC), gathered tensor G (dims gd, channels GC):
@@ -1396,6 +1433,19 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     a.d_sn = dd.sn; a.g_sn = gd.sn;
     a.d_sc4 = (int32_t)(dd.sc * 4); a.d_sd = (int32_t)dd.sd; a.d_sh = (int32_t)dd.sh; a.d_sw = (int32_t)dd.sw;
     a.g_sd = (int32_t)gd.sd; a.g_sh = (int32_t)gd.sh; a.g_sw = (int32_t)gd.sw;
+    // regular (4x4 inner taps, depth taps never padded) form?
+    a.log2nd = -1;
+    if (k[1] * k[2] == 16 && (k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8) && (k[0] == 1 || (p[0] == 0 && s[0] == 1)) &&
+        tc.bj >= 128 && gd.sc * 4 < (1ll << 30)) {
+        a.log2nd = k[0] == 1 ? 0 : k[0] == 2 ? 1 : k[0] == 4 ? 2 : 3;
+        a.g_sc4 = (int32_t)(gd.sc * 4);
+        a.g_sd4 = (int32_t)(gd.sd * 4);
+        for (int t = 0; t < 16; ++t) {
+            const int uh = t / k[2], uw = t % k[2];
+            a.hw_off4[t] = (int32_t)(4 * (uh * gd.sh + uw * gd.sw));
+            a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
+        }
+    }
     if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 64) launch_wgrad<2, 1, 2, 2>(a, tiles, S2, stream);
@@ -1426,9 +1476,10 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
         {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4>},
         {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4>},
         {"thin_gather", (const void*)thin_gather_kernel},
-        {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2>},
-        {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4>},
-        {"wgrad<1,2,1,4>", (const void*)wgrad_gemm_kernel<1, 2, 1, 4>}, {"wgrad<1,1,1,4>", (const void*)wgrad_gemm_kernel<1, 1, 1, 4>},
+        {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
+        {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, false>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2, false>},
+        {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, false>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4, false>},
+        {"wgrad<1,2,1,4>", (const void*)wgrad_gemm_kernel<1, 2, 1, 4, false>}, {"wgrad<1,1,1,4>", (const void*)wgrad_gemm_kernel<1, 1, 1, 4, false>},
     };
     size_t off = 0;
     for (const Item& it : items) {
