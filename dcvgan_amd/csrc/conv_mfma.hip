@@ -352,8 +352,15 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
 // --------------------------------------------------------------------------- //
 typedef __attribute__((address_space(3))) void lds_void;
 
+// up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
+// 4x the workgroups per launch fill the chip and amortise the tail of each class.
+struct GatherArgsPack {
+    GatherArgs c[4];
+};
+
 template <int TOC, int TM, int WOC, int WM>
-__global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgs a) {
+__global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
+    const GatherArgs& a = pack.c[blockIdx.z];
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
     constexpr int XPT = 16 * BM / 256;
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     const int m_t = blockIdx.x / tiles_oc;
     const int oc0 = oc_t * BN;
     const int m0 = m_t * BM;
+    if (m0 >= a.Mp) return;   // classes of one launch can differ by a row/column of positions
 
     const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1021,9 +1029,7 @@ static TileCfg pick_gather_tile(int OC) {
 
 template <int TOC, int TM, int WOC, int WM>
 static void launch_gather(const GatherArgs& a, dim3 grid, hipStream_t s) {
-    static const bool use_dma = getenv("DCV_NO_LDS_DMA") == nullptr;
-    if (a.structured && use_dma) hipLaunchKernelGGL((gather_gemm_dma_kernel<TOC, TM, WOC, WM>), grid, dim3(256), 0, s, a);
-    else if (a.structured) hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, a);
+    if (a.structured) hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, false>), grid, dim3(256), 0, s, a);
 }
 
@@ -1039,6 +1045,23 @@ static int gather_splits(int blocks, int KIT, bool thin) {
     return ks < 1 ? 1 : ks;
 }
 
+// launch the collected classes of one op as a single grid (z = class), then their split-K reduces
+static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& tc, int KS, int OC, hipStream_t stream) {
+    for (int i = n; i < 4; ++i) pend.c[i] = pend.c[0];
+    grid.z = (unsigned)n;
+    if (tc.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, pend);
+    else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4>), grid, dim3(256), 0, stream, pend);
+    else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4>), grid, dim3(256), 0, stream, pend);
+    DCV_LAUNCH_CHECK();
+    if (KS > 1)
+        for (int i = 0; i < n; ++i) {
+            const int64_t tot = (int64_t)OC * pend.c[i].Mp;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, pend.c[i], KS);
+            DCV_LAUNCH_CHECK();
+        }
+    return DCV_OK;
+}
+
 // The generic driver: reduce over `RC` channels of tensor `x` (dims xd) into `OC`
 // channels of tensor `y` (dims yd); classes describe position/tap relations;
 // weight element (oc, rc, kd, kh, kw) lives at oc*ws_o + rc*ws_r + ((kd*KH)+kh)*KW+kw.
@@ -1049,9 +1072,10 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
     const TileCfg tc = pick_gather_tile(OC);
     const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
     size_t ws_off = 0;
-    int ci = 0;
+    GatherArgsPack pend;
+    int npend = 0, KSpend = 1, OCpend = 0;
+    dim3 pend_grid(0, 1, 1);
     for (const GatherClass& c : classes) {
-        ++ci;
         const int T = c.taps[0].n * c.taps[1].n * c.taps[2].n;
         if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
         const int64_t K = (int64_t)RC * T;
@@ -1209,6 +1233,25 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
         }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
+        const bool dma = a.structured && tc.bn != 4 && getenv("DCV_NO_LDS_DMA") == nullptr;
+        if (dma) {   // deferred: merged with the other classes of this op below
+            if (npend > 0 && (pend_grid.y != grid.y || pend.c[0].KIT != a.KIT)) {
+                int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
+                if (rc2 != DCV_OK) return rc2;
+                npend = 0;
+            }
+            pend.c[npend++] = a;
+            if (npend == 1 || grid.x > pend_grid.x) pend_grid.x = grid.x;
+            pend_grid.y = grid.y;
+            KSpend = KS2;
+            OCpend = OC;
+            if (npend == 4) {
+                int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
+                if (rc2 != DCV_OK) return rc2;
+                npend = 0;
+            }
+            continue;
+        }
         if (tc.bn == 4 && thin_struct) {
             const int rcps = KS2 > 1 ? kper * 16 / T : RC;   // whole channels per K split
             if (T == 4) launch_thin_struct<4>(a, OC, RC, rcps, grid, stream);
@@ -1224,6 +1267,10 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, a, KS2);
             DCV_LAUNCH_CHECK();
         }
+    }
+    if (npend > 0) {
+        int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
+        if (rc2 != DCV_OK) return rc2;
     }
     return DCV_OK;
 }
