@@ -23,6 +23,7 @@
 // (KEntry) carry all index arithmetic so one kernel serves every geometry.
 #include "dcv_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -84,6 +85,12 @@ struct GatherArgs {
     int32_t structured, s_log2p, s_stepA, s_stepD;
     int32_t s_local[16];
     uint32_t s_sel[16];
+};
+
+// up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
+// 4x the workgroups per launch fill the chip and amortise the tail of each class.
+struct GatherArgsPack {
+    GatherArgs c[4];
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -352,12 +359,6 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
 // --------------------------------------------------------------------------- //
 typedef __attribute__((address_space(3))) void lds_void;
 
-// up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
-// 4x the workgroups per launch fill the chip and amortise the tail of each class.
-struct GatherArgsPack {
-    GatherArgs c[4];
-};
-
 template <int TOC, int TM, int WOC, int WM>
 __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
     const GatherArgs& a = pack.c[blockIdx.z];
@@ -533,7 +534,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 }
 
 // y = act( sum_s slab[s][oc][m] (+ y) ), scattered to the NCDHW output; fixed summation order.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GatherArgs a, int S) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GatherArgsPack pack, int S) {
+    const GatherArgs& a = pack.c[blockIdx.y];
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int m = (int)(idx % a.Mp), oc = (int)(idx / a.Mp);
     if (m >= a.M || oc >= a.OC) return;
@@ -726,16 +728,21 @@ static bool launch_thin_struct(const GatherArgs& a, int OC, int RC, int rc_per_s
     return false;
 }
 
-// Wp[k][oc] = w[oc * ws_o + ktab[k].w_off]   (zero for padding rows / channels)
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, const KEntry* __restrict__ ktab,
-                                    int K16, int OC, int OCp, int64_t ws_o) {
+// Wp[k][oc] = w[oc * ws_o + ktab[k].w_off]   (zero for padding rows / channels); blockIdx.y = class
+struct PackArgs {
+    const KEntry* ktab[4];
+    float* wp[4];
+    int32_t K16[4];
+};
+__global__ void pack_weights_kernel(const float* __restrict__ w, const PackArgs pa, int OC, int OCp, int64_t ws_o) {
+    const int c = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)K16 * OCp) return;
+    if (i >= (int64_t)pa.K16[c] * OCp) return;
     const int k = (int)(i / OCp), oc = (int)(i % OCp);
-    const KEntry e = ktab[k];
+    const KEntry e = pa.ktab[c][k];
     float v = 0.f;
     if (oc < OC && !(e.tapsel >> 31)) v = w[(int64_t)oc * ws_o + e.w_off];
-    wp[i] = v;
+    pa.wp[c][i] = v;
 }
 
 // --------------------------------------------------------------------------- //
@@ -1046,6 +1053,13 @@ static int gather_splits(int blocks, int KIT, bool thin) {
 }
 
 // launch the collected classes of one op as a single grid (z = class), then their split-K reduces
+static int flush_packs(const float* w, const PackArgs& packs, int n, int kmax, int OC, int OCp, int64_t ws_o, hipStream_t stream) {
+    const int64_t tot = (int64_t)kmax * OCp;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((tot + 255) / 256), (unsigned)n), dim3(256), 0, stream, w, packs, OC, OCp, ws_o);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& tc, int KS, int OC, hipStream_t stream) {
     for (int i = n; i < 4; ++i) pend.c[i] = pend.c[0];
     grid.z = (unsigned)n;
@@ -1053,12 +1067,12 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4>), grid, dim3(256), 0, stream, pend);
     else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4>), grid, dim3(256), 0, stream, pend);
     DCV_LAUNCH_CHECK();
-    if (KS > 1)
-        for (int i = 0; i < n; ++i) {
-            const int64_t tot = (int64_t)OC * pend.c[i].Mp;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, pend.c[i], KS);
-            DCV_LAUNCH_CHECK();
-        }
+    if (KS > 1) {
+        int64_t tot = 0;
+        for (int i = 0; i < n; ++i) tot = std::max<int64_t>(tot, (int64_t)OC * pend.c[i].Mp);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256), (unsigned)n), dim3(256), 0, stream, pend, KS);
+        DCV_LAUNCH_CHECK();
+    }
     return DCV_OK;
 }
 
@@ -1073,6 +1087,9 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
     const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
     size_t ws_off = 0;
     GatherArgsPack pend;
+    PackArgs packs;
+    memset(&packs, 0, sizeof(packs));
+    int npack = 0, packmax = 0;
     int npend = 0, KSpend = 1, OCpend = 0;
     dim3 pend_grid(0, 1, 1);
     for (const GatherClass& c : classes) {
@@ -1139,10 +1156,15 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         ws_off += wp_bytes;
         float* slab = KS2 > 1 ? reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off) : nullptr;
         ws_off += slab_bytes;
-        {
-            const int64_t tot = (int64_t)KIT * 16 * OCp;
-            hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, w, wp, tab.dev, KIT * 16, OC, OCp, ws_o);
-            DCV_LAUNCH_CHECK();
+        packs.ktab[npack] = tab.dev;
+        packs.wp[npack] = wp;
+        packs.K16[npack] = KIT * 16;
+        if (KIT * 16 > packmax) packmax = KIT * 16;
+        if (++npack == 4) {
+            int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
+            if (rcp != DCV_OK) return rcp;
+            npack = 0;
+            packmax = 0;
         }
         // ---- GEMM ----
         GatherArgs a;
@@ -1234,8 +1256,15 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         const bool dma = a.structured && tc.bn != 4 && getenv("DCV_NO_LDS_DMA") == nullptr;
+        if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
+            int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
+            if (rcp != DCV_OK) return rcp;
+            npack = 0;
+            packmax = 0;
+        }
         if (dma) {   // deferred: merged with the other classes of this op below
             if (npend > 0 && (pend_grid.y != grid.y || pend.c[0].KIT != a.KIT)) {
+                if (npack > 0) { int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream); if (rcp != DCV_OK) return rcp; npack = 0; packmax = 0; }
                 int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
                 if (rc2 != DCV_OK) return rc2;
                 npend = 0;
@@ -1246,6 +1275,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             KSpend = KS2;
             OCpend = OC;
             if (npend == 4) {
+                if (npack > 0) { int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream); if (rcp != DCV_OK) return rcp; npack = 0; packmax = 0; }
                 int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
                 if (rc2 != DCV_OK) return rc2;
                 npend = 0;
@@ -1264,9 +1294,15 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         DCV_LAUNCH_CHECK();
         if (KS2 > 1) {
             const int64_t tot = (int64_t)OC * Mp;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, a, KS2);
+            GatherArgsPack one;
+            for (int i = 0; i < 4; ++i) one.c[i] = a;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, stream, one, KS2);
             DCV_LAUNCH_CHECK();
         }
+    }
+    if (npack > 0) {
+        int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
+        if (rcp != DCV_OK) return rcp;
     }
     if (npend > 0) {
         int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
