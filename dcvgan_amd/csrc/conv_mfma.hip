@@ -441,8 +441,21 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
             if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4) /* wave-uniform: whole waves only */                       \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], it_ * wstep4, 0, 0); \
     }
+// the same DMAs, one X row / the W tile at a time (interleaved by hand into the MFMA phase: hipcc
+// will not move an LDS-DMA write across LDS reads)
+#define DCV_ISSUE_XROW(SOFF, BUF, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (BUF) * 16 * BM + lm_wave + (ksub * XPT + (I)) * BM), 4, vloc[I], (SOFF), 0, 0);
+#define DCV_ISSUE_W(IT, BUF)                                                                                            \
+    {                                                                                                                   \
+        float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
+        _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                 \
+            if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4)                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], (IT) * wstep4, 0, 0); \
+    }
 #else
 #define DCV_ISSUE_TILE(IT, BUF) { (void)wstep4; (void)wvo; (void)vloc; (void)lm_wave; }
+#define DCV_ISSUE_XROW(SOFF, BUF, I) { (void)(SOFF); }
+#define DCV_ISSUE_W(IT, BUF) { (void)wstep4; (void)wvo; }
 #endif
 
     f32x16 acc[TOC][TM];
@@ -461,11 +474,14 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         const int buf = (it - it0) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile `it` have landed
         __syncthreads();                                   // ... everyone's have; and all reads of buf^1 are done
-        if (it + 1 < it1) DCV_ISSUE_TILE(it + 1, buf ^ 1)
-        __builtin_amdgcn_sched_barrier(0);
+        // next tile's DMAs (clamped on the last step: a harmless repeat into the idle buffer) are
+        // spread over the k-steps below, two per MFMA group, so their issue cost hides under the MFMAs
+        __builtin_amdgcn_s_setprio(2);
+        const int itn = min(it + 1, it1 - 1);   // last step: a harmless repeat into the idle buffer
+        const int soffn = (itn >> a.s_log2p) * a.s_stepA + (itn & ((1 << a.s_log2p) - 1)) * a.s_stepD;
+        DCV_ISSUE_W(itn, buf ^ 1)
         const float* xt = Xs + buf * 16 * BM;
         const float* wt = Ws + buf * 16 * BN;
-        __builtin_amdgcn_s_setprio(2);
         float af[2][TOC], bf[2][TM];
 #pragma unroll
         for (int i = 0; i < TOC; ++i) af[0][i] = wt[lhi * BN + (woc * TOC + i) * 32 + l31];
@@ -486,12 +502,17 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);
+            // next tile: XPT/8 gathered rows per k-step, issued in the shadow of this step's MFMAs
+#pragma unroll
+            for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_XROW(soffn, buf ^ 1, ks * (XPT / 8) + q)
+            __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);   // next step's fragments first,
+            __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);   // then this step's MFMAs,
+            __builtin_amdgcn_sched_group_barrier(0x010, XPT / 8, 0);    // then the DMA issues in their shadow
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated last-step DMAs must land before LDS is released
 
     if (a.slab) {
         float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
