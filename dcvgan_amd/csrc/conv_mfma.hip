@@ -968,6 +968,141 @@ __global__ __launch_bounds__(256, (TD * TJ >= 4 ? (REG16 ? 3 : 2) : 3)) void wgr
             }
 }
 
+// --------------------------------------------------------------------------- //
+// wgrad GEMM, double-buffered LDS-DMA form (4x4 inner taps, 128 x 128 tile).
+// Tiles are kept [channel row][64 positions] with a pitch of 65 words: every row is ONE
+// lane-linear 256-B buffer_load...lds (positions on the lanes) and the MFMA fragment read
+// "32 channels x one position" hits 32 different banks.  The per-lane voffset carries the
+// position (for the gathered operand one of the 16 (kh,kw) taps, padding folded in as
+// 0x80000000); channel and depth tap ride on the scalar soffset.  Two 66.5 KB buffers = one
+// workgroup per CU, one wave per SIMD: while the 128 MFMAs of a tile run (8192 cycles), the
+// next tile's 64 DMAs per wave are issued two per k-step in their shadow; one barrier per tile.
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
+    constexpr int BD = 128, BJ = 128, P = 65, TILE = (BD + BJ) * P;
+    __shared__ float smem[2 * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wave >> 1, wj = wave & 1;
+    const int tiles_d = a.DCp / BD;
+    const int d_t = blockIdx.x % tiles_d, j_t = blockIdx.x / tiles_d;
+    const int d0 = d_t * BD, j0 = j_t * BJ;
+    const int m_begin = blockIdx.y * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int nit = (m_end > m_begin) ? (m_end - m_begin + 63) / 64 : 0;
+
+    const uint32_t nb = fdiv((uint32_t)(nit > 0 ? m_begin : 0), a.div_sp);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dptr + (int64_t)nb * a.d_sn), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x80000000u, 0x00020000);
+
+    // scalar row offsets of this wave's 32 + 32 rows (loop invariant)
+    const int cd0 = (j0 >> 4) + wave * 2;   // (channel, depth tap) index of rows 0..15; rows 16..31 -> cd0 + 1
+    const int gso0 = (cd0 >> a.log2nd) * a.g_sc4 + (cd0 & ((1 << a.log2nd) - 1)) * a.g_sd4;
+    const int gso1 = ((cd0 + 1) >> a.log2nd) * a.g_sc4 + ((cd0 + 1) & ((1 << a.log2nd) - 1)) * a.g_sd4;
+    const int dso0 = (d0 + wave * 32) * a.d_sc4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint32_t dvo = 0x80000000u, gvo[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) gvo[t] = 0x80000000u;
+
+    // per-lane voffsets of tile IT (position m_begin + IT*64 + lane)
+#define DCV_WG_ADDR(IT)                                                                                                  \
+    {                                                                                                                    \
+        const int m_ = m_begin + (IT) * 64 + lane;                                                                       \
+        const bool mok_ = m_ < m_end;                                                                                    \
+        const int mm_ = mok_ ? m_ : m_begin;                                                                             \
+        const uint32_t n_ = fdiv((uint32_t)mm_, a.div_sp);                                                               \
+        uint32_t r_ = (uint32_t)mm_ - n_ * a.div_sp.div;                                                                 \
+        const uint32_t pd_ = fdiv(r_, a.div_hw);                                                                         \
+        r_ -= pd_ * a.div_hw.div;                                                                                        \
+        const uint32_t ph_ = fdiv(r_, a.div_w);                                                                          \
+        const uint32_t pw_ = r_ - ph_ * a.div_w.div;                                                                     \
+        dvo = mok_ ? (uint32_t)(4 * ((int)((int64_t)(n_ - nb) * a.d_sn) + (int)pd_ * a.d_sd + (int)ph_ * a.d_sh + (int)pw_ * a.d_sw)) : 0x80000000u; \
+        const uint32_t vm_ = mok_ ? (dim_mask(a.th, (int)ph_, 8) | dim_mask(a.tw, (int)pw_, 16)) : 0u;                   \
+        const int gb_ = 4 * ((int)((int64_t)(n_ - nb) * a.g_sn) + ((int)pd_ * a.td.mul + a.td.base) * a.g_sd +           \
+                             ((int)ph_ * a.th.mul + a.th.base) * a.g_sh + ((int)pw_ * a.tw.mul + a.tw.base) * a.g_sw);   \
+        _Pragma("unroll") for (int t = 0; t < 16; ++t)                                                                   \
+            gvo[t] = ((vm_ & a.hw_sel[t]) == a.hw_sel[t]) ? (uint32_t)(gb_ + a.hw_off4[t]) : 0x80000000u;                \
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // row I (0..31) of this wave's dense / gathered share of the tile in buffer BUF
+#define DCV_WG_DROW(BUF, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(smem + (BUF) * TILE + (wave * 32 + (I)) * P), 4, dvo, dso0 + (I) * a.d_sc4, 0, 0);
+#define DCV_WG_GROW(BUF, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void*)(smem + (BUF) * TILE + (BD + wave * 32 + (I)) * P), 4, gvo[(I) & 15], ((I) < 16 ? gso0 : gso1), 0, 0);
+#else
+#define DCV_WG_DROW(BUF, I) { (void)dso0; }
+#define DCV_WG_GROW(BUF, I) { (void)gso0; (void)gso1; }
+#endif
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if (nit > 0) {
+        DCV_WG_ADDR(0)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { DCV_WG_DROW(0, i) DCV_WG_GROW(0, i) }
+        DCV_WG_ADDR(min(1, nit - 1))   // voffsets of the tile whose DMAs the first loop step issues
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int it = 0; it < nit; ++it) {
+        const int buf = it & 1;
+        // dvo / gvo hold tile min(it + 1, nit - 1) (last tile: a harmless repeat into the idle buffer)
+        const float* da = smem + buf * TILE + ((wd * 2) * 32 + l31) * P + lhi;
+        const float* gb = smem + buf * TILE + (BD + (wj * 2) * 32 + l31) * P + lhi;
+        __builtin_amdgcn_s_setprio(2);
+        float af[2][2], bf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { af[0][i] = da[i * 32 * P]; bf[0][i] = gb[i * 32 * P]; }
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 32) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { af[nxt][i] = da[i * 32 * P + 2 * (ks + 1)]; bf[nxt][i] = gb[i * 32 * P + 2 * (ks + 1)]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            DCV_WG_DROW(buf ^ 1, ks)
+            DCV_WG_GROW(buf ^ 1, ks)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        DCV_WG_ADDR(min(it + 2, nit - 1))                  // overlaps the tail MFMAs and the DMA-completion wait
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMAs of the next tile have landed
+        __syncthreads();                                   // ... everyone's; and all reads of `buf` are done
+    }
+
+    float* __restrict__ out = a.slab + (int64_t)blockIdx.y * a.DCp * a.Jp;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dc = d0 + (wd * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int jj = j0 + (wj * 2 + j) * 32 + l31;
+                out[(int64_t)dc * a.Jp + jj] = acc[i][j][r];
+            }
+}
+
 // dw[dc][j] = sum_s slab[s][dc][j].  64 outputs per block; the 4 waves each sum every 4th split
 // (independent loads, 4-way unrolled) and wave 0 combines the four partial sums in a fixed order:
 // bitwise reproducible, and 16x more loads in flight than one thread walking all S splits.
@@ -1464,9 +1599,21 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     const int64_t M64 = (int64_t)dd.n * dd.d * dd.h * dd.w;
     if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
     const int tiles = (DCp / tc.bd) * (Jp / tc.bj);
-    const int S = wgrad_splits(M64, tiles);
+    // double-buffered LDS-DMA form: 128 x 128 tile, 4x4 inner taps, un-padded depth taps, full channel tiles
+    const bool dma = getenv("DCV_NO_WGRAD_DMA") == nullptr && tc.bd == 128 && tc.bj == 128 && k[1] * k[2] == 16 &&
+                     (k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8) && (k[0] == 1 || (p[0] == 0 && s[0] == 1)) &&
+                     DC % 128 == 0 && J % 128 == 0 && gd.sc * 4 < (1ll << 30) && dd.sc * 4 < (1ll << 30);
+    int S;
+    if (dma) {   // one workgroup per CU: whole rounds of 256, >= 1024 positions each
+        S = (512 + tiles - 1) / tiles;
+        const int64_t maxs = (M64 + 1023) / 1024;
+        if (S > maxs) S = (int)maxs;
+        if (S < 1) S = 1;
+    } else {
+        S = wgrad_splits(M64, tiles);
+    }
     int64_t chunk = (M64 + S - 1) / S;
-    chunk = (chunk + 31) / 32 * 32;
+    chunk = (chunk + 63) / 64 * 64;
     const int S2 = (int)((M64 + chunk - 1) / chunk);
     const size_t need = align_up((size_t)S2 * DCp * Jp * sizeof(float), 256);
     if (need_only) {
@@ -1550,7 +1697,8 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
             a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
         }
     }
-    if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
+    if (dma && a.log2nd >= 0) hipLaunchKernelGGL(wgrad_dma_kernel, dim3(tiles, S2), dim3(256), 0, stream, a);
+    else if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 64) launch_wgrad<2, 1, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 64 && tc.bj == 256) launch_wgrad<2, 2, 1, 4>(a, tiles, S2, stream);
@@ -1580,7 +1728,7 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
         {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4>},
         {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4>},
         {"thin_gather", (const void*)thin_gather_kernel},
-        {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
+        {"wgrad_dma", (const void*)wgrad_dma_kernel}, {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
         {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, false>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2, false>},
         {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, false>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4, false>},
         {"wgrad<1,2,1,4>", (const void*)wgrad_gemm_kernel<1, 2, 1, 4, false>}, {"wgrad<1,1,1,4>", (const void*)wgrad_gemm_kernel<1, 1, 1, 4, false>},
