@@ -1003,13 +1003,16 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     const int gso1 = ((cd0 + 1) >> a.log2nd) * a.g_sc4 + ((cd0 + 1) & ((1 << a.log2nd) - 1)) * a.g_sd4;
     const int dso0 = (d0 + wave * 32) * a.d_sc4;
 
-    f32x16 acc[2][2];
+    // two-level accumulation (registers are free at one wave per SIMD): the MFMA adds into `acc` as a
+    // k-ordered fp32 chain; every 16 tiles (1024 positions) the chain is folded into `sum`, so no
+    // partial sum is longer than 1024 terms before it meets a value of its own magnitude
+    f32x16 acc[2][2], sum[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; sum[i][j][r] = 0.f; }
 
     uint32_t dvo = 0x80000000u, gvo[16];
 #pragma unroll
@@ -1084,6 +1087,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        if ((it & 15) == 15) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { sum[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+        }
         DCV_WG_ADDR(min(it + 2, nit - 1))                  // overlaps the tail MFMAs and the DMA-completion wait
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMAs of the next tile have landed
@@ -1099,7 +1110,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int dc = d0 + (wd * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int jj = j0 + (wj * 2 + j) * 32 + l31;
-                out[(int64_t)dc * a.Jp + jj] = acc[i][j][r];
+                out[(int64_t)dc * a.Jp + jj] = sum[i][j][r] + acc[i][j][r];
             }
 }
 

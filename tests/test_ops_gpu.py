@@ -222,3 +222,23 @@ def test_out_slices_and_copy_free_concat(dev):
     got = torch.autograd.grad((y * cot.to(dev)).sum(), [xd] + p)
     for u, v in zip(got, ref):
         assert rel(u, v) < TOL
+
+
+def test_wgrad_long_reduction_accuracy(dev):
+    """Weight gradient over 16384 positions per split-free chain (128x128 tile => the LDS-DMA wgrad kernel
+    with two-level accumulation): error against an fp64 reference must be in the class of torch's own
+    fp32 CPU result (and far inside the 1e-3 bar)."""
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(64, 128, 32, 32, generator=g)
+    w = (torch.randn(128, 128, 4, 4, generator=g) * 0.05)
+    dy = torch.randn(64, 128, 16, 16, generator=g)
+    w64 = w.double().requires_grad_(True)
+    (F.conv2d(x.double(), w64, None, 2, 1) * dy.double()).sum().backward()
+    w32 = w.clone().requires_grad_(True)
+    (F.conv2d(x, w32, None, 2, 1) * dy).sum().backward()
+    xd = x.to(dev); wd = w.to(dev).requires_grad_(True)
+    y = ops.conv(xd, wd, ops.conv_geom(wd, (2, 2), (1, 1), False))
+    (y * dy.to(dev)).sum().backward()
+    e_hip = rel(wd.grad, w64.grad); e_cpu = rel(w32.grad, w64.grad)
+    assert e_hip < 1e-5 and e_hip < 5 * max(e_cpu, 2e-7), (e_hip, e_cpu)
