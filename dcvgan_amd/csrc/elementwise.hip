@@ -599,6 +599,87 @@ __global__ void gru_reduce_kernel(const float* __restrict__ part, int B, int P, 
     else db_hh[i - 2 * w - 3 * dm] = s;
 }
 
+
+// ------------------------------------------------------------------------- //
+// sampling path (util.py:58-79, 198-248): float videos -> uint8 on the device
+// ------------------------------------------------------------------------- //
+// out[b][c*rep + q][t][h][w] = uint8( (clip(x,-1,1) + 1) / 2 * 255 )   (numpy astype: truncation),
+// the same fp32 operation order as the reference so the bytes are identical.  rep = 3 tiles a
+// 1-channel depth video into RGB (util.py:219-222).
+struct ToU8 {
+    const float* x; uint8_t* out; RowView xv; int rep;
+    template <int VEC> __device__ void apply(const RowMap& m, const Pos& p) const {
+        float v[VEC];
+        ld<VEC>(x + offs(m, xv, p), v);
+        const int64_t plane = (int64_t)m.H * m.W;
+        const int64_t col = m.inner == 1 ? (int64_t)p.h * m.W + p.w : p.col;
+        for (int q = 0; q < rep; ++q) {
+            uint8_t* o = out + ((((int64_t)p.n * m.C + p.c) * rep + q) * m.D + p.d) * plane + col;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float t = fminf(fmaxf(v[i], -1.f), 1.f);
+                t = __fmul_rn(__fmul_rn(__fadd_rn(t, 1.f), 0.5f), 255.f);
+                o[i] = (uint8_t)(int)t;
+            }
+        }
+    }
+};
+
+// per-frame min / max of the flow magnitude (one block per (b, t) frame)
+__global__ __launch_bounds__(256) void flow_minmax_kernel(const float* __restrict__ f, RowView fv, int T, int HW, int W, float scale, float* __restrict__ mm) {
+    __shared__ float smin[4], smax[4];
+    const int b = blockIdx.x / T, t = blockIdx.x % T;
+    float lo = 3.4e38f, hi = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int64_t o = (int64_t)b * fv.sn + (int64_t)t * fv.sd + (int64_t)(i / W) * fv.sh + (int64_t)(i % W) * fv.sw;
+        const float x = fminf(fmaxf(f[o], -1.f), 1.f) * scale, y = fminf(fmaxf(f[o + fv.sc], -1.f), 1.f) * scale;
+        const float mg = sqrtf(x * x + y * y);
+        lo = fminf(lo, mg); hi = fmaxf(hi, mg);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[2 * blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        mm[2 * blockIdx.x + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+
+// util.visualize_optical_flow (util.py:143-170): hue = direction (OpenCV 8-bit H = degrees / 2),
+// saturation 255, value = magnitude min-max normalised per frame; HSV -> RGB, uint8 (B,3,T,H,W).
+__global__ __launch_bounds__(256) void flow_to_rgb_kernel(const float* __restrict__ f, RowView fv, int B, int T, int HW, int W, float scale,
+                                                          const float* __restrict__ mm, uint8_t* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * T * HW) return;
+    const int i = (int)(idx % HW);
+    const int bt = (int)(idx / HW), b = bt / T, t = bt % T;
+    const int64_t o = (int64_t)b * fv.sn + (int64_t)t * fv.sd + (int64_t)(i / W) * fv.sh + (int64_t)(i % W) * fv.sw;
+    const float x = fminf(fmaxf(f[o], -1.f), 1.f) * scale, y = fminf(fmaxf(f[o + fv.sc], -1.f), 1.f) * scale;
+    const float mg = sqrtf(x * x + y * y);
+    float ang = atan2f(y, x);
+    if (ang < 0.f) ang += 6.283185307179586f;
+    const int Hh = (int)(ang * 180.f / 3.14159265358979f / 2.f) & 255;        // uint8 assignment truncates
+    const float lo = mm[2 * bt], hi = mm[2 * bt + 1];
+    const int V = hi > lo ? (int)((mg - lo) * (255.f / (hi - lo))) : 0;
+    // HSV (H in [0,180), S = 255, V) -> RGB
+    const float h6 = (float)Hh / 30.f;
+    const int sec = ((int)h6) % 6;
+    const float fr = h6 - floorf(h6), v = (float)V;
+    const float p_ = 0.f, q_ = v * (1.f - fr), t_ = v * fr;
+    float r, g, bl;
+    switch (sec) {
+        case 0: r = v; g = t_; bl = p_; break;
+        case 1: r = q_; g = v; bl = p_; break;
+        case 2: r = p_; g = v; bl = t_; break;
+        case 3: r = p_; g = q_; bl = v; break;
+        case 4: r = t_; g = p_; bl = v; break;
+        default: r = v; g = p_; bl = q_; break;
+    }
+    const int64_t plane = (int64_t)T * HW;
+    uint8_t* ob = out + ((int64_t)b * 3) * plane + (int64_t)t * HW + i;
+    ob[0] = (uint8_t)(int)(r + 0.5f); ob[plane] = (uint8_t)(int)(g + 0.5f); ob[2 * plane] = (uint8_t)(int)(bl + 0.5f);
+}
+
 }  // namespace dcv
 
 using namespace dcv;
@@ -734,6 +815,28 @@ int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+
+int dcv_videos_to_uint8(const float* x, const dcv_dims5* xd, uint8_t* out, int channel_repeat, void* stream) {
+    if (!x || !xd || !out || channel_repeat < 1 || channel_repeat > 4) return fail(DCV_EINVAL, "videos_to_uint8: bad arguments");
+    const dcv_dims5* views[1] = {xd};
+    const void* ptrs[1] = {x};
+    RowMap m = make_rowmap(*xd, views, 1, ptrs);
+    ToU8 f{x, out, rv(*xd), channel_repeat};
+    return launch_ew(m, f, static_cast<hipStream_t>(stream));
+}
+
+int dcv_flow_to_rgb(const float* flow, const dcv_dims5* fd, float scale, uint8_t* out, float* ws_minmax, void* stream) {
+    if (!flow || !fd || !out || !ws_minmax || fd->c != 2) return fail(DCV_EINVAL, "flow_to_rgb: needs a (B,2,T,H,W) flow video");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = fd->n, T = fd->d, HW = fd->h * fd->w;
+    hipLaunchKernelGGL(flow_minmax_kernel, dim3(B * T), dim3(256), 0, s, flow, rv(*fd), T, HW, fd->w, scale, ws_minmax);
+    DCV_LAUNCH_CHECK();
+    const int64_t tot = (int64_t)B * T * HW;
+    hipLaunchKernelGGL(flow_to_rgb_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, flow, rv(*fd), B, T, HW, fd->w, scale, ws_minmax, out);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -132,6 +132,16 @@ int dcv_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, void*
 /* Dropout2d(p) plane mask: mask[i] = Bernoulli(1-p) / (1-p), i < n = N*C (generator.py:211,248) */
 int dcv_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- sampling path: float videos -> uint8 on the device --------------------- *
+ * util.videos_to_numpy (util.py:58-79) and the depth branch of
+ * util.geometric_info_in_color_format (util.py:219-222): out = uint8((clip(x,-1,1)+1)/2*255),
+ * same fp32 operation order (bytes identical); out is contiguous (N, C*channel_repeat, D, H, W).  */
+int dcv_videos_to_uint8(const float* x, const dcv_dims5* xd, uint8_t* out, int channel_repeat, void* stream);
+/* util.visualize_optical_flow (util.py:143-170) for a (B,2,T,H,W) flow video scaled by `scale`
+ * (= H, util.py:227): hue = direction, value = per-frame min-max normalised magnitude; out uint8
+ * (B,3,T,H,W); ws_minmax: 2*B*T floats of scratch. */
+int dcv_flow_to_rgb(const float* flow, const dcv_dims5* fd, float scale, uint8_t* out, float* ws_minmax, void* stream);
+
 /* ---- GAN losses (fused value + gradient) --------------------------------- *
  * loss.py:91-99,123-131 (BCE-with-logits, sum / numel) and loss.py:163-164,
  * 190-191 (hinge / softplus).  kind: 0 = BCE target 1, 1 = BCE target 0,

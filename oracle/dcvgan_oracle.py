@@ -421,3 +421,33 @@ class StepOracle:
             l_gen.backward()
             self.opt["ggen"].step(); self.opt["cgen"].step(); self.opt["ggen"].step()  # :357-359
         return {"loss_idis": l_i.item(), "loss_vdis": l_v.item(), "loss_gdis": l_g.item(), "loss_gen": l_gen.item()}
+
+
+# --------------------------------------------------------------------------- #
+# sampling path   (util.py:31-79, 198-322)
+# --------------------------------------------------------------------------- #
+def videos_to_uint8(x: torch.Tensor):
+    """util.videos_to_numpy (util.py:58-79): clip, (x+1)/2*255 in fp32, astype(uint8)."""
+    import numpy as np
+    v = np.clip(x.detach().cpu().numpy(), -1, 1)
+    return ((v + 1) / 2 * 255).astype("uint8")
+
+
+def depth_to_color(xg: torch.Tensor):
+    """util.generate_samples :306-308 + geometric_info_in_color_format :219-222 (depth)."""
+    import numpy as np
+    v = np.clip(xg.detach().cpu().numpy(), -1, 1)
+    v = np.tile(v, (1, 3, 1, 1, 1))
+    return ((v + 1) / 2 * 255).astype("uint8")
+
+
+def generate_samples_depth(st_g: State, st_c: State, num: int, batchsize: int, T: int, dzc: int, dzm: int, dzcol: int, rng):
+    """util.generate_samples (util.py:251-322) for depth geometry: eval mode, no_grad, truncation to num."""
+    import numpy as np
+    xgs, xcs = [], []
+    with torch.no_grad():
+        for _ in range(0, num, batchsize):
+            xg = ggen_sample_videos(st_g, batchsize, T, dzc, dzm, 1, rng, False)
+            xc = cgen_forward_videos(st_c, xg, dzcol, rng, False)
+            xgs.append(depth_to_color(xg)); xcs.append(videos_to_uint8(xc))
+    return np.concatenate(xgs)[:num], np.concatenate(xcs)[:num]

@@ -290,6 +290,72 @@ def fullwidth_fixture(ref, cfg, name, B=2, seed=99):
     return models
 
 
+def sampling_fixture(ref, cfg, name, seed=4321):
+    """util.generate_samples on the reference generators (depth): uint8 outputs, sub-sampled."""
+    util, generator, discriminator, loss = ref
+    out = {}
+    cfg_meta(out, cfg)
+    models = build_models(ref, cfg, seed)
+    for n in ("ggen", "cgen"):
+        put_state(out, f"init/{n}", models[n].state_dict())
+    out["meta/seed_run"] = np.array(seed + 1)
+    torch.manual_seed(seed + 1)
+    xg, xc = util.generate_samples(models["ggen"], models["cgen"], 3, 2)   # 2 batches of 2, truncated to 3
+    assert xg.dtype == np.uint8 and xg.shape == (3, 3, 16, 64, 64) and xc.shape == (3, 3, 16, 64, 64)
+    out["xg_sub"] = xg.reshape(-1)[::13].copy(); out["xc_sub"] = xc.reshape(-1)[::13].copy()
+    out["xg_sum"] = np.array(int(xg.astype(np.int64).sum())); out["xc_sum"] = np.array(int(xc.astype(np.int64).sum()))
+    g = torch.Generator().manual_seed(seed + 2)
+    v = torch.randn(2, 3, 4, 8, 8, generator=g) * 0.8
+    out["conv_in"] = v.numpy().copy(); out["conv_out"] = util.videos_to_numpy(v)
+    im = torch.randn(2, 3, 8, 8, generator=g) * 0.8
+    out["img_in"] = im.numpy().copy(); out["img_out"] = util.images_to_numpy(im)
+    np.savez(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+def interchange_fixture(ref, name="interchange.json"):
+    """checkpoints written by this repo load into the reference's classes and vice versa
+    (trainer.py:78-86 save_params <-> infer.py:31-36 load_state_dict), incl. the whole-module pickle of
+    trainer.py:70-76 resolved through compat/ (top-level module names)."""
+    import io, json, subprocess, tempfile
+    util, generator, discriminator, loss = ref
+    sys.path.insert(0, "/root/repo")
+    from dcvgan_amd import discriminator as D2, generator as G2
+    pairs = [
+        ("ggen", lambda m: m.GeometricVideoGenerator(40, 10, 1, "depth", 16, 16), generator, G2),
+        ("cgen", lambda m: m.ColorVideoGenerator(1, 10, "depth", 16, 16), generator, G2),
+        ("idis", lambda m: m.ImageDiscriminator(1, 3, True, 0.1, 16), discriminator, D2),
+        ("vdis", lambda m: m.VideoDiscriminator(1, 3, True, 0.1, 16), discriminator, D2),
+        ("gdis", lambda m: m.GradientDiscriminator(1, 3, False, 0.2, 16), discriminator, D2),
+    ]
+    res = {}
+    for nm, make, refmod, mymod in pairs:
+        torch.manual_seed(1); r = make(refmod)
+        torch.manual_seed(2); mine = make(mymod)
+        buf = io.BytesIO(); torch.save(mine.state_dict(), buf); buf.seek(0)      # ours -> reference
+        k1 = r.load_state_dict(torch.load(buf), strict=True)
+        same1 = all(torch.equal(a, b) for a, b in zip(r.state_dict().values(), mine.state_dict().values()))
+        torch.manual_seed(3); r2 = make(refmod)
+        buf = io.BytesIO(); torch.save(r2.state_dict(), buf); buf.seek(0)        # reference -> ours
+        k2 = mine.load_state_dict(torch.load(buf), strict=True)
+        same2 = all(torch.equal(a, b) for a, b in zip(r2.state_dict().values(), mine.state_dict().values()))
+        res[nm] = dict(ours_into_reference=bool(same1 and not k1.missing_keys and not k1.unexpected_keys),
+                       reference_into_ours=bool(same2 and not k2.missing_keys and not k2.unexpected_keys),
+                       keys=list(mine.state_dict().keys()) == list(r.state_dict().keys()))
+    # whole-module pickle written by the REFERENCE (trainer.py:75-76) and opened in a process that only has compat/
+    with tempfile.TemporaryDirectory() as td:
+        torch.manual_seed(4)
+        g = generator.GeometricVideoGenerator(40, 10, 1, "depth", 16, 16)
+        torch.save(g, os.path.join(td, "ggen_model.pth"))
+        code = ("import sys; sys.path[:0] = ['/root/repo/compat', '/root/repo']; import torch; "
+                f"m = torch.load(r'{td}/ggen_model.pth', weights_only=False); "
+                "print(type(m).__module__, type(m).__name__, len(m.state_dict()))")
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd="/tmp")
+        res["reference_pickle_opens_through_compat"] = out.stdout.strip() or out.stderr.strip()[-300:]
+    json.dump(res, open(os.path.join(HERE, name), "w"), indent=1)
+    print("wrote", name, res)
+
+
 if __name__ == "__main__":
     ref = import_reference()
     torch.set_num_threads(8)
@@ -305,3 +371,5 @@ if __name__ == "__main__":
     full = dict(geo="depth", Cg=1, dzc=40, dzm=10, dzcol=10, ngf_g=64, ngf_c=64, ndf_i=64, ndf_v=64, ndf_g=32,
                 noise_i=(True, 0.1), noise_v=(True, 0.1), noise_g=(False, 0.2))
     fullwidth_fixture(ref, full, "fullwidth_isogd_depth.npz")
+    sampling_fixture(ref, dict(small_depth, ngf_g=4, ngf_c=4), "sampling_depth_w4.npz")
+    interchange_fixture(ref)

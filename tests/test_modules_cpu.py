@@ -106,3 +106,28 @@ def test_configs_restated():
     f = CONFIGS["isogd-flow"]
     assert (f.channel, f.geometric_info, f.noise_sigma["idis"]) == (2, "optical-flow", 0.2)
     assert FLOPS_PER_VIDEO_STEP["isogd-depth"][0] == 166.12e9
+
+
+def test_checkpoint_interchange_fixture():
+    """SURVEY §8(f).2 — recorded by tests/golden/make_golden.py where the reference is importable:
+    our state_dicts load (strict) into the reference classes and vice versa, same keys in the same order,
+    and a whole-module pickle written by the reference (trainer.py:75-76) opens through compat/."""
+    import json, os
+    res = json.load(open(os.path.join(G.GOLDEN, "interchange.json")))
+    for n in ("ggen", "cgen", "idis", "vdis", "gdis"):
+        assert res[n] == {"ours_into_reference": True, "reference_into_ours": True, "keys": True}, (n, res[n])
+    assert res["reference_pickle_opens_through_compat"] == "dcvgan_amd.generator GeometricVideoGenerator 29"
+
+
+def test_load_model_like_infer(tmp_path):
+    """infer.py:14-38 flow on our own artefacts: whole-module pickle + params file -> model on the device."""
+    from dcvgan_amd import sampling
+    torch.manual_seed(0)
+    g = Gm.GeometricVideoGenerator(4, 2, 1, "depth", 4, 16)
+    torch.save(g, tmp_path / "ggen_model.pth")
+    torch.manual_seed(1)
+    g2 = Gm.GeometricVideoGenerator(4, 2, 1, "depth", 4, 16)
+    torch.save(g2.state_dict(), tmp_path / "ggen_params_00001.pth")
+    m = sampling.load_model(tmp_path / "ggen_model.pth", tmp_path / "ggen_params_00001.pth", torch.device("cpu"))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), g2.state_dict().values()))
+    assert m.device == torch.device("cpu")

@@ -143,3 +143,14 @@ def test_step(fixture):
 def test_fullwidth_scalars_shapes():
     fx = G.load("fullwidth_isogd_depth.npz")
     assert fx["yi"].shape == (2, 4, 4) and fx["yv"].shape == (2, 4, 4, 4) and fx["yg"].shape == (2, 3, 4, 4)
+
+
+def test_sampling_path():
+    """util.generate_samples / videos_to_numpy / images_to_numpy — uint8, bit-exact."""
+    fx = G.load("sampling_depth_w4.npz"); cfg = G.cfg_of(fx, B=2); st = G.states(fx)
+    torch.manual_seed(int(fx["meta/seed_run"]))
+    xg, xc = O.generate_samples_depth(st["ggen"], st["cgen"], 3, 2, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.dim_z_color, O.TorchRng())
+    assert xg.dtype == np.uint8 and xg.shape == (3, 3, 16, 64, 64) and xc.shape == (3, 3, 16, 64, 64)
+    assert np.array_equal(xg.reshape(-1)[::13], fx["xg_sub"]) and int(xg.astype(np.int64).sum()) == int(fx["xg_sum"])
+    assert np.array_equal(xc.reshape(-1)[::13], fx["xc_sub"]) and int(xc.astype(np.int64).sum()) == int(fx["xc_sum"])
+    assert np.array_equal(O.videos_to_uint8(torch.from_numpy(fx["conv_in"])), fx["conv_out"])
