@@ -680,6 +680,57 @@ __global__ __launch_bounds__(256) void flow_to_rgb_kernel(const float* __restric
     ob[0] = (uint8_t)(int)(r + 0.5f); ob[plane] = (uint8_t)(int)(g + 0.5f); ob[2 * plane] = (uint8_t)(int)(bl + 0.5f);
 }
 
+
+// ------------------------------------------------------------------------- //
+// input pipeline (dataset.py:125-186): frames as read from disk -> training tensors
+// ------------------------------------------------------------------------- //
+// out[b][c][t][h][w] = float(in[b][t][h][w][c]) / div - sub   (numpy's fp32 operation order)
+template <class TIN>
+__global__ __launch_bounds__(256) void decode_video_kernel(const TIN* __restrict__ in, float* __restrict__ out, int64_t BT_per_B /*T*/, int64_t HW, int Cc, int64_t total, float div, float sub) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index over (b, c, t, hw) of the output
+    if (i >= total) return;
+    const int64_t hw = i % HW;
+    int64_t r = i / HW;
+    const int64_t t = r % BT_per_B; r /= BT_per_B;
+    const int c = (int)(r % Cc);
+    const int64_t b = r / Cc;
+    const float v = (float)in[((b * BT_per_B + t) * HW + hw) * Cc + c];
+    out[i] = v / div - sub;
+}
+
+// SURREAL depth (dataset.py:137-156): foreground = depth < 1e10; min-max of the foreground per clip
+__global__ __launch_bounds__(256) void surreal_minmax_kernel(const float* __restrict__ d, int64_t per_clip, float* __restrict__ mm) {
+    __shared__ float smin[4], smax[4];
+    const float* p = d + (int64_t)blockIdx.x * per_clip;
+    float lo = 3.4e38f, hi = -3.4e38f;
+    for (int64_t i = threadIdx.x; i < per_clip; i += 256) {
+        const float v = p[i];
+        if (v < 1e10f) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[2 * blockIdx.x] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+        mm[2 * blockIdx.x + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    }
+}
+__global__ __launch_bounds__(256) void surreal_norm_kernel(const float* __restrict__ d, int64_t per_clip, int64_t total, const float* __restrict__ mm, float* __restrict__ out) {
+#pragma clang fp contract(off)   // numpy rounds h*1.8 before subtracting; no fma
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int64_t b = i / per_clip;
+    const float v = d[i], mi = mm[2 * b], ma = mm[2 * b + 1];
+    float o = 1.0f;                                        // background
+    if (v < 1e10f) {
+        float h = v;
+        if (ma - mi > 0.f) h = (v - mi) / (ma - mi);
+        o = h * 1.8f - 1.0f;                               // [-1.0, 0.8]
+    }
+    out[i] = o;
+}
+
 }  // namespace dcv
 
 using namespace dcv;
@@ -819,6 +870,28 @@ int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     return DCV_OK;
 }
 
+
+int dcv_decode_video(const void* in, int in_is_u8, int B, int T, int H, int W, int Cc, float div, float sub, float* out, void* stream) {
+    if (!in || !out || B < 1 || T < 1 || H < 1 || W < 1 || Cc < 1 || div == 0.f) return fail(DCV_EINVAL, "decode_video: bad arguments");
+    const int64_t total = (int64_t)B * Cc * T * H * W;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (in_is_u8) hipLaunchKernelGGL((decode_video_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, static_cast<const uint8_t*>(in), out, (int64_t)T, (int64_t)H * W, Cc, total, div, sub);
+    else hipLaunchKernelGGL((decode_video_kernel<float>), dim3(grid), dim3(256), 0, s, static_cast<const float*>(in), out, (int64_t)T, (int64_t)H * W, Cc, total, div, sub);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_surreal_depth(const float* depth, int B, int T, int H, int W, float* out, float* ws_minmax, void* stream) {
+    if (!depth || !out || !ws_minmax || B < 1) return fail(DCV_EINVAL, "surreal_depth: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t per = (int64_t)T * H * W, total = per * B;
+    hipLaunchKernelGGL(surreal_minmax_kernel, dim3(B), dim3(256), 0, s, depth, per, ws_minmax);
+    DCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(surreal_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, depth, per, total, ws_minmax, out);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
 
 int dcv_videos_to_uint8(const float* x, const dcv_dims5* xd, uint8_t* out, int channel_repeat, void* stream) {
     if (!x || !xd || !out || channel_repeat < 1 || channel_repeat > 4) return fail(DCV_EINVAL, "videos_to_uint8: bad arguments");

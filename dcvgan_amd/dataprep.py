@@ -1,0 +1,55 @@
+"""Device-side input normalisation: what `VideoDataset.__getitem__`
+(/root/reference/src/dataset.py:125-186) does per clip on the CPU, done per *batch* on the GPU so a
+data-parallel trainer (560 clips/step at 8 GPUs) is not host-bound.  The DataLoader then only has to
+hand over disk-order frames — uint8 (B,T,H,W,C) for images, fp32 (B,T,H,W,2) flow, fp32 (B,T,H,W)
+SURREAL depth — ideally from pinned memory with `non_blocking=True`.
+
+The reference's dataset module cannot be imported here (cv2 / skvideo), so these are restatements of
+its formulas, pinned by the assertions of its own tests (test_dataset.py:32-95), not by executing it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .native import NativeError, check, lib, ptr, stream_ptr
+
+
+def _decode(frames: torch.Tensor, div: float, sub: float) -> torch.Tensor:
+    if not frames.is_cuda or frames.dim() != 5 or not frames.is_contiguous():
+        raise NativeError("decode: expected a contiguous (B,T,H,W,C) tensor on the HIP device")
+    if frames.dtype not in (torch.uint8, torch.float32):
+        raise NativeError(f"decode: uint8 or float32 frames, got {frames.dtype}")
+    B, T, H, W, Cc = frames.shape
+    out = torch.empty((B, Cc, T, H, W), dtype=torch.float32, device=frames.device)
+    check(lib().dcv_decode_video(C.c_void_p(frames.data_ptr()), int(frames.dtype == torch.uint8), B, T, H, W, Cc, div, sub, ptr(out), stream_ptr()),
+          "dcv_decode_video")
+    return out
+
+
+def decode_color(frames_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 (B,T,H,W,3) -> fp32 (B,3,T,H,W) in [-1,1]: x/127.5 - 1 (dataset.py:127-131)."""
+    return _decode(frames_u8, 127.5, 1.0)
+
+
+def decode_depth(frames_u8: torch.Tensor) -> torch.Tensor:
+    """uint8 grayscale (B,T,H,W,1) -> fp32 (B,1,T,H,W) in [-1,1] (dataset.py:158-168)."""
+    return _decode(frames_u8, 127.5, 1.0)
+
+
+def decode_flow(flow: torch.Tensor, image_size: int) -> torch.Tensor:
+    """fp32 (B,T,H,W,2) pixels/frame -> (B,2,T,H,W) / image_size (dataset.py:170-174)."""
+    return _decode(flow, float(image_size), 0.0)
+
+
+def decode_surreal_depth(depth: torch.Tensor) -> torch.Tensor:
+    """fp32 (B,T,H,W) metres with background >= 1e10 -> (B,1,T,H,W): foreground min-max normalised per
+    clip to [-1, 0.8], background 1.0 (dataset.py:137-156)."""
+    if not depth.is_cuda or depth.dim() != 4 or depth.dtype != torch.float32 or not depth.is_contiguous():
+        raise NativeError("decode_surreal_depth: expected a contiguous float32 (B,T,H,W) tensor on the HIP device")
+    B, T, H, W = depth.shape
+    out = torch.empty((B, 1, T, H, W), dtype=torch.float32, device=depth.device)
+    mm = torch.empty(2 * B, dtype=torch.float32, device=depth.device)
+    check(lib().dcv_surreal_depth(ptr(depth), B, T, H, W, ptr(out), ptr(mm), stream_ptr()), "dcv_surreal_depth")
+    return out

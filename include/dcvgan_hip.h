@@ -132,6 +132,15 @@ int dcv_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, void*
 /* Dropout2d(p) plane mask: mask[i] = Bernoulli(1-p) / (1-p), i < n = N*C (generator.py:211,248) */
 int dcv_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- input pipeline (dataset.py:125-186): disk-order frames -> training tensors ----------- *
+ * out (B,C,T,H,W) fp32 = float(in (B,T,H,W,C)) / div - sub, numpy's fp32 operation order:
+ * colour / depth PNG frames: in uint8, div 127.5, sub 1.0 (dataset.py:131, 168);
+ * optical flow: in fp32, div image_size, sub 0 (dataset.py:174).                              */
+int dcv_decode_video(const void* in, int in_is_u8, int B, int T, int H, int W, int C, float div, float sub, float* out, void* stream);
+/* SURREAL depth (dataset.py:137-156): depth (B,T,H,W) fp32 with background >= 1e10 -> out (B,1,T,H,W):
+ * foreground min-max normalised per clip to [-1, 0.8], background 1.0; ws_minmax: 2*B floats.  */
+int dcv_surreal_depth(const float* depth, int B, int T, int H, int W, float* out, float* ws_minmax, void* stream);
+
 /* ---- sampling path: float videos -> uint8 on the device --------------------- *
  * util.videos_to_numpy (util.py:58-79) and the depth branch of
  * util.geometric_info_in_color_format (util.py:219-222): out = uint8((clip(x,-1,1)+1)/2*255),
