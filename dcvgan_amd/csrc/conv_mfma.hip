@@ -71,7 +71,7 @@ struct GatherArgs {
     int32_t OD, OH, OW, pad0;
     DimTaps td, th, tw;
     int64_t x_sn;
-    int32_t x_sd, x_sh, x_sw, pad1;
+    int32_t x_sd, x_sh, x_sw, x_back;   // x_back: DSTEP base shift, elements
     int64_t y_sn, y_sc, y_sd, y_sh, y_sw, y_off;
     int32_t act, accumulate;
     float slope, pad2;
@@ -359,7 +359,11 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
 // --------------------------------------------------------------------------- //
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int TOC, int TM, int WOC, int WM>
+// DSTEP (structured == 2): a K step is (4 channels, ONE depth tap, 2x2 inner taps) — the 3-D discriminators'
+// data gradients, where 20-30 % of the (position, depth tap) pairs are padding.  Steps whose depth tap is
+// outside the tensor for every position of the tile are skipped outright; for the rest the tap's validity
+// is OR-ed into the per-lane voffsets (one VALU op per DMA).
+template <int TOC, int TM, int WOC, int WM, bool DSTEP>
 __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
     const GatherArgs& a = pack.c[blockIdx.z];
     constexpr int BN = 32 * TOC * WOC;
@@ -385,8 +389,10 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     if (m0 >= a.Mp) return;   // classes of one launch can differ by a row/column of positions
 
     const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
+    // DSTEP: the scalar depth-tap offset counts up from the farthest tap, so the base sits x_back elements
+    // before the sample (addresses below the tensor are only ever formed for padding, which is not read)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x + (int64_t)n0 * a.x_sn), 0, 0x80000000u, 0x00020000);
+        const_cast<float*>(a.x + (int64_t)n0 * a.x_sn - (DSTEP ? a.x_back : 0)), 0, 0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.wp), 0, 0x80000000u, 0x00020000);
 
@@ -426,6 +432,26 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     }
     const int wstep4 = 16 * a.OCp * 4;
 
+    // DSTEP: depth tap of step `it` is ud = nd-1 - (it & (nd-1)) (ascending addresses); its validity bit
+    // for this lane's position is bit ud of vmask; an invalid tap turns every voffset of the step into padding
+    const int ndm1 = (1 << a.s_log2p) - 1;
+#define DCV_DFLAG(IT) (DSTEP ? ((((vmask >> (ndm1 - ((IT) & ndm1))) & 1u) ^ 1u) << 31) : 0u)
+    uint32_t dmask = 0xffu;   // depth taps that any position of the tile can use
+    if constexpr (DSTEP) {   // bitwise OR over the block (word 0 of the tile memory as scratch, before any DMA)
+        uint32_t wm = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (__ballot((vmask >> u) & 1u)) wm |= 1u << u;
+        uint32_t* sc = reinterpret_cast<uint32_t*>(smem);
+        if (tid == 0) *sc = 0;
+        __syncthreads();
+        if (lane == 0) atomicOr(sc, wm);
+        __syncthreads();
+        dmask = *sc;
+        __syncthreads();
+    }
+#define DCV_STEP_LIVE(IT) ((dmask >> (ndm1 - ((IT) & ndm1))) & 1u)
+
     // The host pass type-checks builtins without gfx950 target features and rejects the 16-byte
     // LDS-DMA size, which silently drops the kernel's host stub: device pass only.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -433,9 +459,10 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     {                                                                                                                   \
         const int it_ = (IT);                                                                                           \
         const int soff_ = (it_ >> a.s_log2p) * a.s_stepA + (it_ & ((1 << a.s_log2p) - 1)) * a.s_stepD;                  \
+        const uint32_t df_ = DCV_DFLAG(it_);                                                                            \
         float* xb_ = Xs + (BUF) * 16 * BM + lm_wave;                                                                    \
         _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(xb_ + (ksub * XPT + i) * BM), 4, vloc[i], soff_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(xb_ + (ksub * XPT + i) * BM), 4, vloc[i] | df_, soff_, 0, 0); \
         float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                 \
             if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4) /* wave-uniform: whole waves only */                       \
@@ -443,8 +470,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     }
 // the same DMAs, one X row / the W tile at a time (interleaved by hand into the MFMA phase: hipcc
 // will not move an LDS-DMA write across LDS reads)
-#define DCV_ISSUE_XROW(SOFF, BUF, I) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (BUF) * 16 * BM + lm_wave + (ksub * XPT + (I)) * BM), 4, vloc[I], (SOFF), 0, 0);
+#define DCV_ISSUE_XROW(SOFF, DF, BUF, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (BUF) * 16 * BM + lm_wave + (ksub * XPT + (I)) * BM), 4, vloc[I] | (DF), (SOFF), 0, 0);
 #define DCV_ISSUE_W(IT, BUF)                                                                                            \
     {                                                                                                                   \
         float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
@@ -454,7 +481,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     }
 #else
 #define DCV_ISSUE_TILE(IT, BUF) { (void)wstep4; (void)wvo; (void)vloc; (void)lm_wave; }
-#define DCV_ISSUE_XROW(SOFF, BUF, I) { (void)(SOFF); }
+#define DCV_ISSUE_XROW(SOFF, DF, BUF, I) { (void)(SOFF); (void)(DF); }
 #define DCV_ISSUE_W(IT, BUF) { (void)wstep4; (void)wvo; }
 #endif
 
@@ -469,16 +496,26 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     const int it0 = a.slab ? blockIdx.y * a.kper : 0;
     const int it1 = a.slab ? min(a.KIT, it0 + a.kper) : a.KIT;
     const int l31 = lane & 31, lhi = lane >> 5;
-    DCV_ISSUE_TILE(it0, 0)
-    for (int it = it0; it < it1; ++it) {
-        const int buf = (it - it0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of tile `it` have landed
+    const int nst = it1 - it0;
+#define DCV_IT(J) (it0 + (J))
+    int j0 = 0;
+    if constexpr (DSTEP)
+        while (j0 < nst && !DCV_STEP_LIVE(DCV_IT(j0))) ++j0;
+    if (j0 < nst) DCV_ISSUE_TILE(DCV_IT(j0), 0)
+    int buf = 0;
+    for (int j = j0; j < nst; buf ^= 1) {
+        int nx = j + 1;
+        if constexpr (DSTEP)
+            while (nx < nst && !DCV_STEP_LIVE(DCV_IT(nx))) ++nx;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of the current tile have landed
         __syncthreads();                                   // ... everyone's have; and all reads of buf^1 are done
         // next tile's DMAs (clamped on the last step: a harmless repeat into the idle buffer) are
         // spread over the k-steps below, two per MFMA group, so their issue cost hides under the MFMAs
         __builtin_amdgcn_s_setprio(2);
-        const int itn = min(it + 1, it1 - 1);   // last step: a harmless repeat into the idle buffer
+        const int itn = DCV_IT(nx < nst ? nx : j);   // last step: a harmless repeat into the idle buffer
         const int soffn = (itn >> a.s_log2p) * a.s_stepA + (itn & ((1 << a.s_log2p) - 1)) * a.s_stepD;
+        const uint32_t dfn = DCV_DFLAG(itn);
+        j = nx;
         DCV_ISSUE_W(itn, buf ^ 1)
         const float* xt = Xs + buf * 16 * BM;
         const float* wt = Ws + buf * 16 * BN;
@@ -504,7 +541,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             // next tile: XPT/8 gathered rows per k-step, issued in the shadow of this step's MFMAs
 #pragma unroll
-            for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_XROW(soffn, buf ^ 1, ks * (XPT / 8) + q)
+            for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_XROW(soffn, dfn, buf ^ 1, ks * (XPT / 8) + q)
             __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);   // next step's fragments first,
             __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);   // then this step's MFMAs,
             __builtin_amdgcn_sched_group_barrier(0x010, XPT / 8, 0);    // then the DMA issues in their shadow
@@ -1230,9 +1267,13 @@ static int flush_packs(const float* w, const PackArgs& packs, int n, int kmax, i
 static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& tc, int KS, int OC, hipStream_t stream) {
     for (int i = n; i < 4; ++i) pend.c[i] = pend.c[0];
     grid.z = (unsigned)n;
-    if (tc.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, pend);
-    else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4>), grid, dim3(256), 0, stream, pend);
-    else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4>), grid, dim3(256), 0, stream, pend);
+    if (pend.c[0].structured == 2) {
+        if (tc.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, pend);
+        else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4, true>), grid, dim3(256), 0, stream, pend);
+        else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4, true>), grid, dim3(256), 0, stream, pend);
+    } else if (tc.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, pend);
+    else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4, false>), grid, dim3(256), 0, stream, pend);
+    else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4, false>), grid, dim3(256), 0, stream, pend);
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
@@ -1266,11 +1307,24 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         const int KIT = (int)((K + 15) / 16);
         const int64_t M64 = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
         if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
+        // ---- depth-step K order?  (scatter form, stride-1 depth with taps that leave the tensor) ----
+        bool dstep = false;
+        {
+            const DimTaps& t0 = c.taps[0];
+            const int nd = t0.n;
+            if (tc.bn != 4 && (nd == 2 || nd == 4 || nd == 8) && c.taps[1].n * c.taps[2].n == 4 && RC % 4 == 0 && t0.mul == 1 &&
+                xd.sc * 16 < (1ll << 30) && xd.sd * 4 * nd < (1ll << 30) && getenv("DCV_NO_LDS_DMA") == nullptr && getenv("DCV_NO_DSTEP") == nullptr) {
+                bool consecutive = true;
+                for (int u = 0; u < nd; ++u) consecutive = consecutive && t0.delta[u] == -u;
+                const bool padded = t0.base - (nd - 1) < 0 || c.o_ext[0] - 1 + t0.base >= t0.size;
+                dstep = consecutive && padded;
+            }
+        }
         // ---- K table (cached) ----
         std::string key(tag);
         {
             char buf[512];
-            int nn = snprintf(buf, sizeof(buf), "|g|%d|%d|%lld|%lld|%d|%d|%lld|%lld|%lld|%lld|", RC, OC, (long long)ws_o, (long long)ws_r, KH, KW,
+            int nn = snprintf(buf, sizeof(buf), "|g%d|%d|%d|%lld|%lld|%d|%d|%lld|%lld|%lld|%lld|", (int)dstep, RC, OC, (long long)ws_o, (long long)ws_r, KH, KW,
                               (long long)xd.sc, (long long)xd.sd, (long long)xd.sh, (long long)xd.sw);
             key.append(buf, nn);
             for (int d = 0; d < 3; ++d) {
@@ -1291,10 +1345,22 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         if (!tab.dev) {
             std::vector<KEntry> host((size_t)KIT * 16);
             size_t k = 0;
-            for (int rc = 0; rc < RC; ++rc)
-                for (int ud = 0; ud < c.taps[0].n; ++ud)
-                    for (int uh = 0; uh < c.taps[1].n; ++uh)
-                        for (int uw = 0; uw < c.taps[2].n; ++uw) {
+            // K order (rc, ud, uh, uw); depth-step order: (rc / 4, ud descending, rc % 4, uh, uw)
+            const int ND = c.taps[0].n, NI = c.taps[1].n * c.taps[2].n;
+            for (int64_t kk = 0; kk < K; ++kk) {
+                int rc, ud, ui;
+                if (dstep) {
+                    ui = (int)(kk % NI);
+                    const int rcl = (int)(kk / NI % 4);
+                    ud = ND - 1 - (int)(kk / (NI * 4) % ND);
+                    rc = (int)(kk / ((int64_t)NI * 4 * ND)) * 4 + rcl;
+                } else {
+                    ui = (int)(kk % NI);
+                    ud = (int)(kk / NI % ND);
+                    rc = (int)(kk / ((int64_t)NI * ND));
+                }
+                const int uh = ui / c.taps[2].n, uw = ui % c.taps[2].n;
+                        {
                             KEntry e;
                             const int64_t xo = (int64_t)rc * xd.sc + (int64_t)c.taps[0].delta[ud] * xd.sd +
                                                (int64_t)c.taps[1].delta[uh] * xd.sh + (int64_t)c.taps[2].delta[uw] * xd.sw;
@@ -1305,6 +1371,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                             e.pad = 0;
                             host[k++] = e;
                         }
+            }
             for (; k < host.size(); ++k) host[k] = KEntry{0, 1u << 31, 0, 0};
             int rc_ = get_table(key, host, &tab);
             if (rc_ != DCV_OK) return rc_;
@@ -1396,6 +1463,18 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             a.structured = 0;
             if (tc.bn == 4) {
                 // thin kernels have their own (per-tap) structured walk, set up above
+            } else if (dstep) {
+                // step = (4 channels, one depth tap, 2x2 inner taps); depth taps walk upwards from the farthest one
+                a.structured = 2;
+                a.s_log2p = nd == 2 ? 1 : nd == 4 ? 2 : 3;
+                a.s_stepA = (int32_t)(sc4 * 4);
+                a.s_stepD = (int32_t)(4 * xd.sd);
+                a.x_back = (int32_t)((nd - 1) * xd.sd);
+                for (int r = 0; r < 16; ++r) {
+                    const int rcl = r / 4, uh = (r % 4) / nw, uw = r % nw;
+                    a.s_local[r] = (int32_t)(4 * (rcl * xd.sc + c.taps[1].delta[uh] * xd.sh + c.taps[2].delta[uw] * xd.sw));
+                    a.s_sel[r] = (1u << (8 + uh)) | (1u << (16 + uw));
+                }
             } else if (16 % T == 0 && RC % (16 / T) == 0 && sc4 * (16 / T) < (1ll << 30)) {
                 // every step covers 16/T whole channels with all T taps
                 a.structured = 1;
@@ -1736,8 +1815,8 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
     const Item items[] = {
         {"gather<2,2,2,2,S>", (const void*)gather_gemm_kernel<2, 2, 2, 2, true>}, {"gather<2,2,1,4,S>", (const void*)gather_gemm_kernel<2, 2, 1, 4, true>},
         {"gather<1,2,1,4,S>", (const void*)gather_gemm_kernel<1, 2, 1, 4, true>}, {"gather<2,2,2,2,T>", (const void*)gather_gemm_kernel<2, 2, 2, 2, false>},
-        {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4>},
-        {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4>},
+        {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, false>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4, false>},
+        {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4, false>}, {"gather_dma_dstep<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, true>},
         {"thin_gather", (const void*)thin_gather_kernel},
         {"wgrad_dma", (const void*)wgrad_dma_kernel}, {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
         {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, false>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2, false>},

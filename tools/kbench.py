@@ -42,6 +42,14 @@ add("gdis.5 conv3d 32->64", False, 32, 64, K3, S3, P3, (B, 32, 12, 32, 32), 3, 3
 add("gdis.9 conv3d 64->128", False, 64, 128, K3, S3, P3, (B, 64, 9, 16, 16), 3, 3, 3)
 add("gdis.13 conv3d 128->1", False, 128, 1, K3, S3, P3, (B, 128, 6, 8, 8), 3, 3, 3)
 
+import os
+if os.environ.get("KSWEEP"):
+    L = []
+    for cin in (32, 64, 128, 256, 512, 1024):
+        add(f"sweep conv {cin}->128 s2 @32", False, cin, 128, (4, 4), (2, 2), (1, 1), (F, cin, 32, 32), 1, 0, 0)
+    for cin in (32, 64, 128, 256, 512, 1024):
+        add(f"sweep conv {cin}->64 s2 @32", False, cin, 64, (4, 4), (2, 2), (1, 1), (F, cin, 32, 32), 1, 0, 0)
+
 def timeit(fn, reps=3):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
