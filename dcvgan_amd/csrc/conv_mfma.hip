@@ -99,17 +99,82 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t dim_mask(const DimTaps& t, int o, int shift) {
+// straight-line (no scalar branches): the whole descriptor is read with wide scalar loads up front
+__device__ __forceinline__ uint32_t dim_mask(const DimTaps t, int o, int shift) {
     uint32_t m = 0;
     const int p0 = o * t.mul + t.base;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        if (u < t.n) {
-            const int p = p0 + t.delta[u];
-            if ((unsigned)p < (unsigned)t.size) m |= 1u << (shift + u);
-        }
+        const int p = p0 + t.delta[u];
+        m |= ((unsigned)p < (unsigned)t.size && u < t.n) ? (1u << (shift + u)) : 0u;
     }
     return m;
+}
+
+
+// --------------------------------------------------------------------------- //
+// Epilogue of the gather GEMMs: scatter a wave's TOC x TM accumulator tiles to the strided output.
+// Raw buffer stores: the per-lane voffset (position, + the lane's 4-row half) is computed once per
+// 32-position column, the output channel rides on the scalar soffset, so a store costs one VMEM and
+// one SALU instruction; lanes past M carry the out-of-range voffset and are dropped by the hardware.
+// (The first version re-derived a 64-bit pointer and re-read its kernel arguments for every one of the
+// 64 stores: 80k cycles per wave, a quarter of a workgroup's lifetime on the short-K layers.)
+// --------------------------------------------------------------------------- //
+template <int TOC, int TM, int ACT, bool GENERIC>
+__device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TOC][TM], const __amdgpu_buffer_rsrc_t yrs, const uint32_t (&voff)[TM],
+                                            const int ocw, const int lhi, const int OC, const uint32_t y_sc4, const int act, const float slope,
+                                            const bool accumulate) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TOC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ocr = i * 32 + (r & 3) + 8 * (r >> 2);
+                const uint32_t soff = (uint32_t)(ocw + ocr) * y_sc4;
+                float v = acc[i][j][r];
+                uint32_t vo = voff[j];
+                if constexpr (GENERIC) {
+                    if (ocw + ocr + 4 * lhi >= OC) vo = 0x80000000u;
+                    if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, vo, soff, 0));
+                    v = apply_act(v, act, slope);
+                } else {
+                    if constexpr (ACT == DCV_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                    if constexpr (ACT == DCV_ACT_TANH) v = tanhf(v);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), yrs, vo, soff, 0);
+            }
+}
+
+// per-lane byte offset of position m (relative to sample n0's output) + the lane's 4-row half
+__device__ __forceinline__ uint32_t out_voffset(const GatherArgs& a, int m, uint32_t n0, int lhi, uint32_t y_sc4) {
+    if (m >= a.M) return 0x80000000u;
+    const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+    uint32_t r0 = (uint32_t)m - n * a.div_sp.div;
+    const uint32_t od = fdiv(r0, a.div_hw);
+    r0 -= od * a.div_hw.div;
+    const uint32_t oh = fdiv(r0, a.div_w);
+    const uint32_t ow = r0 - oh * a.div_w.div;
+    return 4u * (uint32_t)((int)(n - n0) * (int)a.y_sn + (int)od * (int)a.y_sd + (int)oh * (int)a.y_sh + (int)ow * (int)a.y_sw) + (uint32_t)(4 * lhi) * y_sc4;
+}
+
+template <int TOC, int TM>
+__device__ __forceinline__ void gather_epilogue(const GatherArgs& a, const f32x16 (&acc)[TOC][TM], int m0, int mcol0, int l31, int lhi, int ocw, uint32_t n0) {
+    const int OC = a.OC, OCp = a.OCp, act = a.act;
+    const bool accumulate = a.accumulate != 0;
+    const float slope = a.slope;
+    const uint32_t y_sc4 = (uint32_t)a.y_sc * 4u;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_off + (int64_t)n0 * a.y_sn, 0, 0x80000000u, 0x00020000);
+    uint32_t voff[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) voff[j] = out_voffset(a, m0 + mcol0 + j * 32 + l31, n0, lhi, y_sc4);
+    if (OC == OCp && !accumulate) {
+        if (act == DCV_ACT_NONE) store_tiles<TOC, TM, DCV_ACT_NONE, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false);
+        else if (act == DCV_ACT_LEAKY) store_tiles<TOC, TM, DCV_ACT_LEAKY, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false);
+        else store_tiles<TOC, TM, DCV_ACT_TANH, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false);
+    } else {
+        store_tiles<TOC, TM, 0, true>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, accumulate);
+    }
 }
 
 // --------------------------------------------------------------------------- //
@@ -366,6 +431,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 template <int TOC, int TM, int WOC, int WM, bool DSTEP>
 __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
     const GatherArgs& a = pack.c[blockIdx.z];
+#ifdef DCV_EXP_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef DCV_STAMP
+    const unsigned long long q_start = clock64();
+    unsigned long long q_wait = 0, q_loop = 0;
+#endif
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
     constexpr int XPT = 16 * BM / 256;
@@ -416,11 +488,16 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         }
     }
     uint32_t vloc[XPT];
+    {
+        // this wave's XPT table rows: two wide scalar loads instead of 2 * XPT single ones, each with its wait
+        typedef int32_t i32xp __attribute__((ext_vector_type(XPT)));
+        const i32xp sl = *reinterpret_cast<const i32xp*>(a.s_local + ksub * XPT);
+        const i32xp ss = *reinterpret_cast<const i32xp*>(a.s_sel + ksub * XPT);
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-        const int r = ksub * XPT + i;
-        const uint32_t sel = a.s_sel[r];
-        vloc[i] = ((vmask & sel) == sel) ? (uint32_t)(xbase4 + a.s_local[r]) : 0x80000000u;
+        for (int i = 0; i < XPT; ++i) {
+            const uint32_t sel = (uint32_t)ss[i];
+            vloc[i] = ((vmask & sel) == sel) ? (uint32_t)(xbase4 + sl[i]) : 0x80000000u;
+        }
     }
     // W tile: float4 index f = tid + 256 j -> row f / (BN/4), column 4 (f % (BN/4)); LDS offset = 4 f floats
     uint32_t wvo[WPT];
@@ -503,12 +580,17 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         while (j0 < nst && !DCV_STEP_LIVE(DCV_IT(j0))) ++j0;
     if (j0 < nst) DCV_ISSUE_TILE(DCV_IT(j0), 0)
     int buf = 0;
+#ifdef DCV_STAMP
+    const unsigned long long q_pro = clock64();
+#endif
     for (int j = j0; j < nst; buf ^= 1) {
         int nx = j + 1;
         if constexpr (DSTEP)
             while (nx < nst && !DCV_STEP_LIVE(DCV_IT(nx))) ++nx;
+        STAMP(q0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs of the current tile have landed
         __syncthreads();                                   // ... everyone's have; and all reads of buf^1 are done
+        STAMP(q1);
         // next tile's DMAs (clamped on the last step: a harmless repeat into the idle buffer) are
         // spread over the k-steps below, two per MFMA group, so their issue cost hides under the MFMAs
         __builtin_amdgcn_s_setprio(2);
@@ -540,16 +622,42 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             // next tile: XPT/8 gathered rows per k-step, issued in the shadow of this step's MFMAs
+#ifndef DCV_EXP_NODMA
 #pragma unroll
             for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_XROW(soffn, dfn, buf ^ 1, ks * (XPT / 8) + q)
+#endif
             __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);   // next step's fragments first,
             __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);   // then this step's MFMAs,
             __builtin_amdgcn_sched_group_barrier(0x010, XPT / 8, 0);    // then the DMA issues in their shadow
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DCV_STAMP
+        { unsigned long long q2 = clock64(); q_wait += q1 - q0; q_loop += q2 - q1; }
+#endif
     }
+#ifdef DCV_STAMP
+    const unsigned long long q_fw = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated last-step DMAs must land before LDS is released
+#ifdef DCV_EXP_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef DCV_STAMP
+    const unsigned long long q_epi = clock64();
+#define DCV_STAMP_OUT()                                                                                      \
+    if (lane == 0) {                                                                                         \
+        const unsigned bid_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                \
+        if (bid_ < 4096) {                                                                                   \
+            unsigned long long* g = g_stamp[bid_][wave];                                                     \
+            const unsigned long long q_end = clock64();                                                      \
+            g[0] = q_pro - q_start; g[1] = q_wait; g[2] = q_loop; g[3] = (q_end - q_epi) | ((q_epi - q_fw) << 32); g[4] = q_end - q_start; g[5] = (unsigned long long)nst; \
+        }                                                                                                    \
+    }
+#else
+#define DCV_STAMP_OUT()
+#endif
 
     if (a.slab) {
         float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
@@ -562,33 +670,11 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
                     const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     sl[(int64_t)oc * a.Mp + m0 + (wm * TM + j) * 32 + l31] = acc[i][j][r];
                 }
+        DCV_STAMP_OUT()
         return;
     }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + (wm * TM + j) * 32 + l31;
-        if (m >= a.M) continue;
-        const uint32_t n = fdiv((uint32_t)m, a.div_sp);
-        uint32_t r0 = (uint32_t)m - n * a.div_sp.div;
-        const uint32_t od = fdiv(r0, a.div_hw);
-        r0 -= od * a.div_hw.div;
-        const uint32_t oh = fdiv(r0, a.div_w);
-        const uint32_t ow = r0 - oh * a.div_w.div;
-        float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
-#pragma unroll
-        for (int i = 0; i < TOC; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (oc < a.OC) {
-                    float v = acc[i][j][r];
-                    float* p = yb + (int64_t)oc * a.y_sc;
-                    if (a.accumulate) v += *p;
-                    *p = apply_act(v, a.act, a.slope);
-                }
-            }
-        }
-    }
+    gather_epilogue<TOC, TM>(a, acc, m0, wm * TM * 32, l31, lhi, oc0 + woc * TOC * 32, n0);
+    DCV_STAMP_OUT()
 }
 
 // y = act( sum_s slab[s][oc][m] (+ y) ), scattered to the NCDHW output; fixed summation order.
@@ -856,7 +942,7 @@ __global__ __launch_bounds__(256, (TD * TJ >= 4 ? (REG16 ? 3 : 2) : 3)) void wgr
     // outside the tensors (padding taps, ragged tails) get offset 0x80000000 -> hardware returns 0
     const uint32_t nb = fdiv((uint32_t)(nit > 0 ? m_begin : 0), a.div_sp);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dptr + (int64_t)nb * a.d_sn), 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x40000000u, 0x00020000);
 
     // this thread's J rows (gathered channel, tap) are fixed for the whole reduction
     int32_t goff4[REG16 ? 1 : JPT];
@@ -1015,6 +1101,35 @@ __global__ __launch_bounds__(256, (TD * TJ >= 4 ? (REG16 ? 3 : 2) : 3)) void wgr
 // workgroup per CU, one wave per SIMD: while the 128 MFMAs of a tile run (8192 cycles), the
 // next tile's 64 DMAs per wave are issued two per k-step in their shadow; one barrier per tile.
 // --------------------------------------------------------------------------- //
+// Per-lane voffsets of one 64-position tile (position m on this lane).  4x4 inner taps: the gathered
+// operand's offset is plane + row(kh) + col(kw); an invalid row / column / position contributes
+// 0x40000000 = num_records of the descriptor (block-relative offsets stay below it), so any sum with
+// an invalid part is out of range and the DMA writes 0 — 8 range tests and 16 adds instead of 16
+// mask tests, and straight-line code that the scheduler can spread under the MFMAs.
+__device__ __forceinline__ void wgrad_tile_addr(const WgradArgs& a, int m, int m_begin, int m_end, uint32_t nb, uint32_t& dvo, uint32_t (&gvo)[16]) {
+    const bool mok = m < m_end;
+    const int mm = mok ? m : m_begin;
+    const uint32_t n = fdiv((uint32_t)mm, a.div_sp);
+    uint32_t r = (uint32_t)mm - n * a.div_sp.div;
+    const uint32_t pd = fdiv(r, a.div_hw);
+    r -= pd * a.div_hw.div;
+    const uint32_t ph = fdiv(r, a.div_w);
+    const uint32_t pw = r - ph * a.div_w.div;
+    const int ns = (int)(n - nb);
+    dvo = mok ? (uint32_t)(4 * (ns * (int)a.d_sn + (int)pd * a.d_sd + (int)ph * a.d_sh + (int)pw * a.d_sw)) : 0x80000000u;
+    const uint32_t plane = mok ? (uint32_t)(4 * (ns * (int)a.g_sn + ((int)pd * a.td.mul + a.td.base) * a.g_sd)) : 0x40000000u;
+    const int h0 = (int)ph * a.th.mul + a.th.base, w0 = (int)pw * a.tw.mul + a.tw.base;
+    uint32_t row[4], col[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int hp = h0 + u, wp = w0 + u;
+        row[u] = plane + ((unsigned)hp < (unsigned)a.th.size ? (uint32_t)(hp * a.g_sh * 4) : 0x40000000u);
+        col[u] = (unsigned)wp < (unsigned)a.tw.size ? (uint32_t)(wp * a.g_sw * 4) : 0x40000000u;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) gvo[t] = row[t >> 2] + col[t & 3];
+}
+
 __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     constexpr int BD = 128, BJ = 128, P = 65, TILE = (BD + BJ) * P;
     __shared__ float smem[2 * TILE];
@@ -1032,7 +1147,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 
     const uint32_t nb = fdiv((uint32_t)(nit > 0 ? m_begin : 0), a.div_sp);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dptr + (int64_t)nb * a.d_sn), 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gptr + (int64_t)nb * a.g_sn), 0, 0x40000000u, 0x00020000);
 
     // scalar row offsets of this wave's 32 + 32 rows (loop invariant)
     const int cd0 = (j0 >> 4) + wave * 2;   // (channel, depth tap) index of rows 0..15; rows 16..31 -> cd0 + 1
@@ -1051,29 +1166,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; sum[i][j][r] = 0.f; }
 
-    uint32_t dvo = 0x80000000u, gvo[16];
+    uint32_t dvo = 0x80000000u, gvo[16], dvon = 0x80000000u, gvon[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) gvo[t] = 0x80000000u;
-
-    // per-lane voffsets of tile IT (position m_begin + IT*64 + lane)
-#define DCV_WG_ADDR(IT)                                                                                                  \
-    {                                                                                                                    \
-        const int m_ = m_begin + (IT) * 64 + lane;                                                                       \
-        const bool mok_ = m_ < m_end;                                                                                    \
-        const int mm_ = mok_ ? m_ : m_begin;                                                                             \
-        const uint32_t n_ = fdiv((uint32_t)mm_, a.div_sp);                                                               \
-        uint32_t r_ = (uint32_t)mm_ - n_ * a.div_sp.div;                                                                 \
-        const uint32_t pd_ = fdiv(r_, a.div_hw);                                                                         \
-        r_ -= pd_ * a.div_hw.div;                                                                                        \
-        const uint32_t ph_ = fdiv(r_, a.div_w);                                                                          \
-        const uint32_t pw_ = r_ - ph_ * a.div_w.div;                                                                     \
-        dvo = mok_ ? (uint32_t)(4 * ((int)((int64_t)(n_ - nb) * a.d_sn) + (int)pd_ * a.d_sd + (int)ph_ * a.d_sh + (int)pw_ * a.d_sw)) : 0x80000000u; \
-        const uint32_t vm_ = mok_ ? (dim_mask(a.th, (int)ph_, 8) | dim_mask(a.tw, (int)pw_, 16)) : 0u;                   \
-        const int gb_ = 4 * ((int)((int64_t)(n_ - nb) * a.g_sn) + ((int)pd_ * a.td.mul + a.td.base) * a.g_sd +           \
-                             ((int)ph_ * a.th.mul + a.th.base) * a.g_sh + ((int)pw_ * a.tw.mul + a.tw.base) * a.g_sw);   \
-        _Pragma("unroll") for (int t = 0; t < 16; ++t)                                                                   \
-            gvo[t] = ((vm_ & a.hw_sel[t]) == a.hw_sel[t]) ? (uint32_t)(gb_ + a.hw_off4[t]) : 0x80000000u;                \
-    }
+    for (int t = 0; t < 16; ++t) { gvo[t] = 0x80000000u; gvon[t] = 0x80000000u; }
+#define DCV_WG_ADDR(IT, DVO, GVO) wgrad_tile_addr(a, m_begin + (IT) * 64 + lane, m_begin, m_end, nb, DVO, GVO);
 #if defined(__HIP_DEVICE_COMPILE__)
     // row I (0..31) of this wave's dense / gathered share of the tile in buffer BUF
 #define DCV_WG_DROW(BUF, I) \
@@ -1087,20 +1183,27 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 
     const int l31 = lane & 31, lhi = lane >> 5;
     if (nit > 0) {
-        DCV_WG_ADDR(0)
+        DCV_WG_ADDR(0, dvo, gvo)
 #pragma unroll
         for (int i = 0; i < 32; ++i) { DCV_WG_DROW(0, i) DCV_WG_GROW(0, i) }
-        DCV_WG_ADDR(min(1, nit - 1))   // voffsets of the tile whose DMAs the first loop step issues
+        DCV_WG_ADDR(min(1, nit - 1), dvo, gvo)   // voffsets of the tile whose DMAs the first loop step issues
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef DCV_STAMP
+    unsigned long long s_mfma = 0, s_addr = 0, s_wait = 0, s_t0 = clock64();
+#endif
     for (int it = 0; it < nit; ++it) {
         const int buf = it & 1;
+        STAMP(w0);
         // dvo / gvo hold tile min(it + 1, nit - 1) (last tile: a harmless repeat into the idle buffer)
         const float* da = smem + buf * TILE + ((wd * 2) * 32 + l31) * P + lhi;
         const float* gb = smem + buf * TILE + (BD + (wj * 2) * 32 + l31) * P + lhi;
         __builtin_amdgcn_s_setprio(2);
+        // voffsets of the tile after next: plain VALU work with no consumer inside this step, free to be
+        // scheduled into the shadow of the MFMAs below (one wave per SIMD: nothing else would hide it)
+        DCV_WG_ADDR(min(it + 2, nit - 1), dvon, gvon)
         float af[2][2], bf[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { af[0][i] = da[i * 32 * P]; bf[0][i] = gb[i * 32 * P]; }
@@ -1116,14 +1219,20 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-            DCV_WG_DROW(buf ^ 1, ks)
-            DCV_WG_GROW(buf ^ 1, ks)
+            // next tile's 64 row DMAs, three per k-step: the last one is issued at k-step 21 and has
+            // ten k-steps (2500 cycles) to land before the wait at the end of the tile
+#pragma unroll
+            for (int q = 3 * ks; q < 3 * ks + 3; ++q)
+                if (q < 64) {
+                    if (q & 1) { DCV_WG_GROW(buf ^ 1, q >> 1) } else { DCV_WG_DROW(buf ^ 1, q >> 1) }
+                }
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+            if (ks < 21) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
+            else if (ks == 21) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+        STAMP(w1);
         if ((it & 15) == 15) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -1132,11 +1241,22 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { sum[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
         }
-        DCV_WG_ADDR(min(it + 2, nit - 1))                  // overlaps the tail MFMAs and the DMA-completion wait
-        __builtin_amdgcn_sched_barrier(0);
+        dvo = dvon;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) gvo[t] = gvon[t];
+        STAMP(w2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMAs of the next tile have landed
         __syncthreads();                                   // ... everyone's; and all reads of `buf` are done
+#ifdef DCV_STAMP
+        { unsigned long long w3 = clock64(); s_mfma += w1 - w0; s_addr += w2 - w1; s_wait += w3 - w2; }
+#endif
     }
+#ifdef DCV_STAMP
+    if (lane == 0 && blockIdx.x + blockIdx.y * gridDim.x < 4096) {
+        unsigned long long* g = g_stamp[blockIdx.x + blockIdx.y * gridDim.x][wave];
+        g[0] = s_mfma; g[1] = s_addr; g[2] = s_wait; g[3] = 0; g[4] = clock64() - s_t0; g[5] = (unsigned long long)nit;
+    }
+#endif
 
     float* __restrict__ out = a.slab + (int64_t)blockIdx.y * a.DCp * a.Jp;
 #pragma unroll
@@ -1428,6 +1548,10 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             const int64_t span = (tc.bm / per + 2) * (xd.sn < 0 ? -xd.sn : xd.sn) + (int64_t)RC * (xd.sc < 0 ? -xd.sc : xd.sc);
             if (span >= (1ll << 29) || xd.sd > INT32_MAX / 256 || xd.sh > INT32_MAX / 256 || xd.sw > INT32_MAX / 256)
                 return fail(DCV_EUNSUPPORTED, "%s: input too large for 32-bit block offsets", tag);
+            // the epilogue's buffer stores: sample-relative byte offsets below 2^31, channel offsets below 2^32
+            const int64_t yspan = (tc.bm / per + 2) * yd.sn + (int64_t)yd.d * yd.sd + (int64_t)yd.h * yd.sh + (int64_t)yd.w * yd.sw + 8 * yd.sc;
+            if (yd.sn < 0 || yd.sc < 0 || yd.sd < 0 || yd.sh < 0 || yd.sw < 0 || yspan >= (1ll << 29) || (int64_t)OCp * yd.sc >= (1ll << 30))
+                return fail(DCV_EUNSUPPORTED, "%s: output too large for 32-bit block offsets", tag);
         }
         a.x_sd = (int32_t)xd.sd;
         a.x_sh = (int32_t)xd.sh;
@@ -1690,20 +1814,25 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
     const int tiles = (DCp / tc.bd) * (Jp / tc.bj);
     // double-buffered LDS-DMA form: 128 x 128 tile, 4x4 inner taps, un-padded depth taps, full channel tiles
-    const bool dma = getenv("DCV_NO_WGRAD_DMA") == nullptr && tc.bd == 128 && tc.bj == 128 && k[1] * k[2] == 16 &&
-                     (k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8) && (k[0] == 1 || (p[0] == 0 && s[0] == 1)) &&
-                     DC % 128 == 0 && J % 128 == 0 && gd.sc * 4 < (1ll << 30) && dd.sc * 4 < (1ll << 30);
-    int S;
+    bool dma = getenv("DCV_NO_WGRAD_DMA") == nullptr && tc.bd == 128 && tc.bj == 128 && k[1] == 4 && k[2] == 4 &&
+               (k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8) && (k[0] == 1 || (p[0] == 0 && s[0] == 1)) &&
+               DC % 128 == 0 && J % 128 == 0 && gd.sc * 4 < (1ll << 30) && dd.sc * 4 < (1ll << 30);
+    int S = 1;
+    int64_t chunk = 0;
     if (dma) {   // one workgroup per CU: whole rounds of 256, >= 1024 positions each
         S = (512 + tiles - 1) / tiles;
         const int64_t maxs = (M64 + 1023) / 1024;
         if (S > maxs) S = (int)maxs;
         if (S < 1) S = 1;
-    } else {
-        S = wgrad_splits(M64, tiles);
+        chunk = ((M64 + S - 1) / S + 63) / 64 * 64;
+        // its padding encoding needs the gathered operand's block-relative byte offsets below 2^30
+        const int64_t per = (int64_t)dd.d * dd.h * dd.w;
+        if ((chunk / per + 2) * gd.sn * 4 >= (1ll << 30)) dma = false;
     }
-    int64_t chunk = (M64 + S - 1) / S;
-    chunk = (chunk + 63) / 64 * 64;
+    if (!dma) {
+        S = wgrad_splits(M64, tiles);
+        chunk = ((M64 + S - 1) / S + 63) / 64 * 64;
+    }
     const int S2 = (int)((M64 + chunk - 1) / chunk);
     const size_t need = align_up((size_t)S2 * DCp * Jp * sizeof(float), 256);
     if (need_only) {
