@@ -85,6 +85,15 @@ struct GatherArgs {
     int32_t structured, s_log2p, s_stepA, s_stepD;
     int32_t s_local[16];
     uint32_t s_sel[16];
+    // patch staging (w-contiguous operand, OW | tile): instead of one gathered row per (channel, tap), the raw
+    // input rows each output row of the tile needs are copied once — NH rows of IW + 8 words (a zero granule
+    // on either side) per (channel, output row) — as 16-byte LDS-DMA granules; the MFMA fragment reads do the
+    // gathering (per-lane patch address + per-k-row scalar offset s_local[r]).  2-4 DMAs per wave and step
+    // instead of 8-16.
+    int32_t patch, p_G, p_log2nh, p_log2tr;   // granules per step; rows per (channel, output row); output rows per tile
+    int32_t p_log2ow, p_iwp, p_ihmin, p_iwmin4;
+    int32_t p_dw1, p_sc4, p_pad1, p_pad2;     // word step from an even k row to the next (tap uw -> uw + 1); channel stride in bytes
+    FastDiv p_gpr;                            // granules per patch row = IW / 4 + 2
 };
 
 // up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
@@ -428,18 +437,24 @@ typedef __attribute__((address_space(3))) void lds_void;
 // data gradients, where 20-30 % of the (position, depth tap) pairs are padding.  Steps whose depth tap is
 // outside the tensor for every position of the tile are skipped outright; for the rest the tap's validity
 // is OR-ed into the per-lane voffsets (one VALU op per DMA).
-template <int TOC, int TM, int WOC, int WM, bool DSTEP>
+template <int TOC, int TM, int WOC, int WM, bool DSTEP, bool PATCH>
 __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
-    const GatherArgs& a = pack.c[blockIdx.z];
-#ifdef DCV_EXP_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    constexpr int BN = 32 * TOC * WOC;
+    constexpr int BM = 32 * TM * WM;
+    // XCD-aware workgroup -> tile mapping.  Workgroup ids go round-robin over the 8 XCDs, each with its own
+    // L2: the workgroups that read the SAME gathered operand (the op's stride-parity classes and the
+    // output-channel tiles of one position tile) are given ids 8 apart, i.e. the same XCD back to back, so
+    // the operand is fetched into one L2 once instead of into up to 8 of them at different times.
+    const unsigned tiles_oc_ = (unsigned)pack.c[0].OCp / BN, ncls_ = (unsigned)pack.c[0].pad0;
+    const unsigned grp_ = tiles_oc_ * ncls_, loc_ = blockIdx.x >> 3;
+    const unsigned g_ = loc_ % grp_;
+    const int m_t = (int)((loc_ / grp_) * 8 + (blockIdx.x & 7));
+    const int oc_t = (int)(g_ % tiles_oc_);
+    const GatherArgs& a = pack.c[g_ / tiles_oc_];
 #ifdef DCV_STAMP
     const unsigned long long q_start = clock64();
     unsigned long long q_wait = 0, q_loop = 0;
 #endif
-    constexpr int BN = 32 * TOC * WOC;
-    constexpr int BM = 32 * TM * WM;
     constexpr int XPT = 16 * BM / 256;
     constexpr int WF4 = 16 * BN / 4;
     constexpr int WPT = (WF4 + 255) / 256;
@@ -453,12 +468,9 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int woc = wave / WM, wm = wave % WM;
-    const int tiles_oc = a.OCp / BN;
-    const int oc_t = blockIdx.x % tiles_oc;
-    const int m_t = blockIdx.x / tiles_oc;
     const int oc0 = oc_t * BN;
     const int m0 = m_t * BM;
-    if (m0 >= a.Mp) return;   // classes of one launch can differ by a row/column of positions
+    if (m0 >= a.Mp) return;   // grid padding; classes of one launch can differ by a row/column of positions
 
     const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
     // DSTEP: the scalar depth-tap offset counts up from the farthest tap, so the base sits x_back elements
@@ -471,8 +483,46 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     const int lm = tid % BM;
     const int ksub = __builtin_amdgcn_readfirstlane(tid / BM);
     const int lm_wave = __builtin_amdgcn_readfirstlane(lm - lane);   // first position column of this wave
+    const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr int NS = XPT / 4;   // patch form: 16-byte DMA slots per wave and step (the X buffer holds 4 * BM granules)
+    uint32_t vmask = 0;           // gathered form: this lane's position; patch form: OR of the slots' depth bits
+    uint32_t vloc[PATCH ? NS : XPT];
+    uint32_t dmrow[PATCH ? NS : 1];
+    uint32_t fb[PATCH ? TM : 1];
+    if constexpr (PATCH) {
+        const uint32_t GPR = a.p_gpr.div;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            // granule q of the step's patch: ((channel * TR + output row) * NH + input row) * GPR + column granule
+            const uint32_t q = (uint32_t)((sl * 4 + wave) * 64 + lane);
+            const uint32_t q1 = fdiv(q, a.p_gpr);
+            const int c = (int)(q - q1 * GPR) - 1;                      // input columns 4c .. 4c + 3 (c = -1, IW/4: zero halo)
+            const int khp = (int)(q1 & ((1u << a.p_log2nh) - 1));
+            const uint32_t q2 = q1 >> a.p_log2nh;
+            const int t = (int)(q2 & ((1u << a.p_log2tr) - 1));
+            const int ch = (int)(q2 >> a.p_log2tr);
+            const int m = m0 + (t << a.p_log2ow);
+            const uint32_t mm = (uint32_t)(m < a.M ? m : m0);
+            const uint32_t n = fdiv(mm, a.div_sp);
+            uint32_t r = mm - n * a.div_sp.div;
+            const uint32_t od = fdiv(r, a.div_hw);
+            r -= od * a.div_hw.div;
+            const uint32_t oh = fdiv(r, a.div_w);
+            const int ih = (int)oh * a.th.mul + a.p_ihmin + khp;
+            const bool ok = (int)q < a.p_G && m < a.M && (unsigned)ih < (unsigned)a.th.size && (unsigned)(4 * c) < (unsigned)a.tw.size;
+            vloc[sl] = ok ? (uint32_t)(4 * ((int)((int64_t)(n - n0) * a.x_sn) + ((int)od * a.td.mul + a.td.base) * a.x_sd + ih * a.x_sh + 4 * c) + ch * a.p_sc4)
+                          : 0x80000000u;
+            dmrow[sl] = ok ? dim_mask(a.td, (int)od, 0) : 0u;
+            vmask |= dmrow[sl];
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int col = (wm * TM + j) * 32 + l31;
+            const int t = col >> a.p_log2ow, ow = col & ((1 << a.p_log2ow) - 1);
+            fb[j] = (uint32_t)(4 * (((t << a.p_log2nh) * a.p_iwp) + ow * a.tw.mul + a.p_iwmin4 + lhi * a.p_dw1));
+        }
+    } else {
     int xbase4 = 0;
-    uint32_t vmask = 0;
     {
         const int m = m0 + lm;
         if (m < a.M) {
@@ -487,7 +537,6 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
                           ((int)oh * a.th.mul + a.th.base) * a.x_sh + ((int)ow * a.tw.mul + a.tw.base) * a.x_sw);
         }
     }
-    uint32_t vloc[XPT];
     {
         // this wave's XPT table rows: two wide scalar loads instead of 2 * XPT single ones, each with its wait
         typedef int32_t i32xp __attribute__((ext_vector_type(XPT)));
@@ -498,6 +547,17 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
             const uint32_t sel = (uint32_t)ss[i];
             vloc[i] = ((vmask & sel) == sel) ? (uint32_t)(xbase4 + sl[i]) : 0x80000000u;
         }
+    }
+    dmrow[0] = 0;
+    fb[0] = 0;
+    }
+    // patch form: byte offset of k rows 0, 2, .. 14 of a step inside the patch (odd rows: one tap further, in fb)
+    int32_t koff[8];
+    {
+        typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+        const i32x16 sl16 = *reinterpret_cast<const i32x16*>(a.s_local);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) koff[k] = PATCH ? sl16[2 * k] : 0;
     }
     // W tile: float4 index f = tid + 256 j -> row f / (BN/4), column 4 (f % (BN/4)); LDS offset = 4 f floats
     uint32_t wvo[WPT];
@@ -513,6 +573,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     // for this lane's position is bit ud of vmask; an invalid tap turns every voffset of the step into padding
     const int ndm1 = (1 << a.s_log2p) - 1;
 #define DCV_DFLAG(IT) (DSTEP ? ((((vmask >> (ndm1 - ((IT) & ndm1))) & 1u) ^ 1u) << 31) : 0u)
+#define DCV_DFLAG_SLOT(IT, S) (DSTEP ? ((((dmrow[S] >> (ndm1 - ((IT) & ndm1))) & 1u) ^ 1u) << 31) : 0u)
     uint32_t dmask = 0xffu;   // depth taps that any position of the tile can use
     if constexpr (DSTEP) {   // bitwise OR over the block (word 0 of the tile memory as scratch, before any DMA)
         uint32_t wm = 0;
@@ -532,23 +593,26 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     // The host pass type-checks builtins without gfx950 target features and rejects the 16-byte
     // LDS-DMA size, which silently drops the kernel's host stub: device pass only.
 #if defined(__HIP_DEVICE_COMPILE__)
+// one X DMA: gathered form = k row ksub*XPT + I (dword per lane); patch form = granule slot I (16 bytes per lane)
+#define DCV_ISSUE_X(IT, SOFF, BUF, I)                                                                                   \
+    {                                                                                                                   \
+        if constexpr (PATCH)                                                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (BUF) * 16 * BM + (((I) * 4 + wave) * 64) * 4), 16, \
+                                                     vloc[(I) < NS ? (I) : 0] | DCV_DFLAG_SLOT(IT, (I) < NS ? (I) : 0), (SOFF), 0, 0); \
+        else                                                                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (BUF) * 16 * BM + lm_wave + (ksub * XPT + (I)) * BM), 4, \
+                                                     vloc[I] | DCV_DFLAG(IT), (SOFF), 0, 0);                            \
+    }
 #define DCV_ISSUE_TILE(IT, BUF)                                                                                         \
     {                                                                                                                   \
         const int it_ = (IT);                                                                                           \
         const int soff_ = (it_ >> a.s_log2p) * a.s_stepA + (it_ & ((1 << a.s_log2p) - 1)) * a.s_stepD;                  \
-        const uint32_t df_ = DCV_DFLAG(it_);                                                                            \
-        float* xb_ = Xs + (BUF) * 16 * BM + lm_wave;                                                                    \
-        _Pragma("unroll") for (int i = 0; i < XPT; ++i)                                                                 \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(xb_ + (ksub * XPT + i) * BM), 4, vloc[i] | df_, soff_, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < (PATCH ? NS : XPT); ++i) DCV_ISSUE_X(it_, soff_, BUF, i)                  \
         float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                 \
             if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4) /* wave-uniform: whole waves only */                       \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], it_ * wstep4, 0, 0); \
     }
-// the same DMAs, one X row / the W tile at a time (interleaved by hand into the MFMA phase: hipcc
-// will not move an LDS-DMA write across LDS reads)
-#define DCV_ISSUE_XROW(SOFF, DF, BUF, I) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (BUF) * 16 * BM + lm_wave + (ksub * XPT + (I)) * BM), 4, vloc[I] | (DF), (SOFF), 0, 0);
 #define DCV_ISSUE_W(IT, BUF)                                                                                            \
     {                                                                                                                   \
         float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
@@ -557,8 +621,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], (IT) * wstep4, 0, 0); \
     }
 #else
-#define DCV_ISSUE_TILE(IT, BUF) { (void)wstep4; (void)wvo; (void)vloc; (void)lm_wave; }
-#define DCV_ISSUE_XROW(SOFF, DF, BUF, I) { (void)(SOFF); (void)(DF); }
+#define DCV_ISSUE_TILE(IT, BUF) { (void)wstep4; (void)wvo; (void)vloc; (void)lm_wave; (void)dmrow; }
+#define DCV_ISSUE_X(IT, SOFF, BUF, I) { (void)(SOFF); }
 #define DCV_ISSUE_W(IT, BUF) { (void)wstep4; (void)wvo; }
 #endif
 
@@ -572,7 +636,6 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 
     const int it0 = a.slab ? blockIdx.y * a.kper : 0;
     const int it1 = a.slab ? min(a.KIT, it0 + a.kper) : a.KIT;
-    const int l31 = lane & 31, lhi = lane >> 5;
     const int nst = it1 - it0;
 #define DCV_IT(J) (it0 + (J))
     int j0 = 0;
@@ -596,7 +659,6 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         __builtin_amdgcn_s_setprio(2);
         const int itn = DCV_IT(nx < nst ? nx : j);   // last step: a harmless repeat into the idle buffer
         const int soffn = (itn >> a.s_log2p) * a.s_stepA + (itn & ((1 << a.s_log2p) - 1)) * a.s_stepD;
-        const uint32_t dfn = DCV_DFLAG(itn);
         j = nx;
         DCV_ISSUE_W(itn, buf ^ 1)
         const float* xt = Xs + buf * 16 * BM;
@@ -605,7 +667,9 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
         for (int i = 0; i < TOC; ++i) af[0][i] = wt[lhi * BN + (woc * TOC + i) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < TM; ++j) bf[0][j] = xt[lhi * BM + (wm * TM + j) * 32 + l31];
+        for (int j = 0; j < TM; ++j)
+            bf[0][j] = PATCH ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xt) + (fb[PATCH ? j : 0] + (uint32_t)koff[0]))
+                             : xt[lhi * BM + (wm * TM + j) * 32 + l31];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
@@ -614,21 +678,26 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
                 for (int i = 0; i < TOC; ++i) af[nxt][i] = wt[k * BN + (woc * TOC + i) * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < TM; ++j) bf[nxt][j] = xt[k * BM + (wm * TM + j) * 32 + l31];
+                for (int j = 0; j < TM; ++j)
+                    bf[nxt][j] = PATCH ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xt) + (fb[PATCH ? j : 0] + (uint32_t)koff[ks + 1 < 8 ? ks + 1 : 0]))
+                                       : xt[k * BM + (wm * TM + j) * 32 + l31];
             }
 #pragma unroll
             for (int i = 0; i < TOC; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-            // next tile: XPT/8 gathered rows per k-step, issued in the shadow of this step's MFMAs
-#ifndef DCV_EXP_NODMA
+            // next tile's X DMAs in the shadow of this step's MFMAs: gathered form XPT/8 rows per k-step,
+            // patch form one granule slot in each of the first NS k-steps
+            if constexpr (PATCH) {
+                if (ks < NS) DCV_ISSUE_X(itn, soffn, buf ^ 1, ks)
+            } else {
 #pragma unroll
-            for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_XROW(soffn, dfn, buf ^ 1, ks * (XPT / 8) + q)
-#endif
+                for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_X(itn, soffn, buf ^ 1, ks * (XPT / 8) + q)
+            }
             __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);   // next step's fragments first,
             __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);   // then this step's MFMAs,
-            __builtin_amdgcn_sched_group_barrier(0x010, XPT / 8, 0);    // then the DMA issues in their shadow
+            if (!PATCH || ks < NS) __builtin_amdgcn_sched_group_barrier(0x010, PATCH ? 1 : XPT / 8, 0);   // then the DMA issues in their shadow
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1386,14 +1455,25 @@ static int flush_packs(const float* w, const PackArgs& packs, int n, int kmax, i
 
 static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& tc, int KS, int OC, hipStream_t stream) {
     for (int i = n; i < 4; ++i) pend.c[i] = pend.c[0];
-    grid.z = (unsigned)n;
-    if (pend.c[0].structured == 2) {
-        if (tc.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, stream, pend);
-        else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4, true>), grid, dim3(256), 0, stream, pend);
-        else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4, true>), grid, dim3(256), 0, stream, pend);
-    } else if (tc.bn == 128) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 2, 2, false>), grid, dim3(256), 0, stream, pend);
-    else if (tc.bn == 64) hipLaunchKernelGGL((gather_gemm_dma_kernel<2, 2, 1, 4, false>), grid, dim3(256), 0, stream, pend);
-    else hipLaunchKernelGGL((gather_gemm_dma_kernel<1, 2, 1, 4, false>), grid, dim3(256), 0, stream, pend);
+    {   // grid.x comes in as the largest class's (oc tiles x position tiles); see the kernel's id -> tile mapping
+        const unsigned tiles_oc = (unsigned)(pend.c[0].OCp / tc.bn);
+        const unsigned ntm = (grid.x + tiles_oc - 1) / tiles_oc;
+        grid.x = (ntm + 7) / 8 * 8 * tiles_oc * (unsigned)n;
+        grid.z = 1;
+        pend.c[0].pad0 = n;
+    }
+    const bool ds = pend.c[0].structured == 2, pt = pend.c[0].patch != 0;
+#define DCV_LAUNCH_DMA(A, B, C_, D)                                                                                           \
+    {                                                                                                                         \
+        if (ds && pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, true>), grid, dim3(256), 0, stream, pend);      \
+        else if (ds) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, false>), grid, dim3(256), 0, stream, pend);      \
+        else if (pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, true>), grid, dim3(256), 0, stream, pend);      \
+        else hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, false>), grid, dim3(256), 0, stream, pend);             \
+    }
+    if (tc.bn == 128) DCV_LAUNCH_DMA(2, 2, 2, 2)
+    else if (tc.bn == 64) DCV_LAUNCH_DMA(2, 2, 1, 4)
+    else DCV_LAUNCH_DMA(1, 2, 1, 4)
+#undef DCV_LAUNCH_DMA
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
@@ -1624,6 +1704,53 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                 }
             }
         }
+        // ---- patch staging? (w-contiguous operand, whole output rows per tile, aligned 16-byte granules) ----
+        if (a.structured && tc.bn != 4 && getenv("DCV_NO_PATCH") == nullptr) {
+            const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n;
+            int CH = 0;   // channels per K step; a step holds ONE depth tap
+            if (a.structured == 2) CH = 4;
+            else if (a.s_log2p > 0 || (nd == 1 && nh * nw == 16)) CH = 1;
+            else if (nd == 1 && 16 % (nh * nw) == 0) CH = 16 / (nh * nw);
+            const int OW = c.o_ext[2], IW = c.taps[2].size;
+            auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+            auto span = [](const DimTaps& t, int* dmin) {   // taps cover a contiguous range of n offsets?
+                int lo = t.delta[0], hi = t.delta[0];
+                for (int u = 1; u < t.n; ++u) { lo = std::min(lo, t.delta[u]); hi = std::max(hi, t.delta[u]); }
+                *dmin = lo;
+                return hi - lo + 1 == t.n;
+            };
+            int dminh = 0, dminw = 0;
+            const bool contig = span(c.taps[1], &dminh) && span(c.taps[2], &dminw);
+            const int dw1 = nw >= 2 ? c.taps[2].delta[1] - c.taps[2].delta[0] : 0;
+            const bool pairs = (nw == 2 || nw == 4) && (dw1 == 1 || dw1 == -1) && (nw == 2 || c.taps[2].delta[3] - c.taps[2].delta[2] == dw1);
+            const int iwmin = c.taps[2].base + dminw;
+            const int IWp = IW + 8, GPR = IW / 4 + 2;
+            const int l2nh = ilog2(nh), l2ow = ilog2(OW);
+            const bool aligned = xd.sw == 1 && IW % 4 == 0 && xd.sh % 4 == 0 && xd.sc % 4 == 0 && xd.sd % 4 == 0 && xd.sn % 4 == 0 &&
+                                 (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (a.structured != 2 || a.x_back % 4 == 0);
+            if (CH > 0 && CH * nh * nw == 16 && contig && pairs && l2nh >= 0 && l2ow >= 0 && OW <= tc.bm && aligned && iwmin >= -4 &&
+                (OW - 1) * c.taps[2].mul + iwmin + nw - 1 <= IW + 3 && xd.sc * 4 * CH < (1ll << 30)) {
+                const int TR = tc.bm / OW;
+                const int G = CH * TR * nh * GPR;
+                if (G <= 4 * tc.bm) {
+                    a.patch = 1;
+                    a.p_G = G;
+                    a.p_log2nh = l2nh;
+                    a.p_log2tr = ilog2(TR);
+                    a.p_log2ow = l2ow;
+                    a.p_iwp = IWp;
+                    a.p_ihmin = c.taps[1].base + dminh;
+                    a.p_iwmin4 = iwmin + 4;
+                    a.p_dw1 = dw1;
+                    a.p_sc4 = (int32_t)(xd.sc * 4);
+                    a.p_gpr = make_fastdiv((uint32_t)GPR);
+                    for (int r = 0; r < 16; ++r) {
+                        const int t = r % (nh * nw), chr = r / (nh * nw), uh = t / nw, uw = t % nw;
+                        a.s_local[r] = 4 * (chr * (TR * nh * IWp) + (c.taps[1].delta[uh] - dminh) * IWp + (c.taps[2].delta[uw] - dminw));
+                    }
+                }
+            }
+        }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         const bool dma = a.structured && tc.bn != 4 && getenv("DCV_NO_LDS_DMA") == nullptr;
         if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
@@ -1633,7 +1760,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             packmax = 0;
         }
         if (dma) {   // deferred: merged with the other classes of this op below
-            if (npend > 0 && (pend_grid.y != grid.y || pend.c[0].KIT != a.KIT)) {
+            if (npend > 0 && (pend_grid.y != grid.y || pend.c[0].KIT != a.KIT || pend.c[0].patch != a.patch)) {
                 if (npack > 0) { int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream); if (rcp != DCV_OK) return rcp; npack = 0; packmax = 0; }
                 int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
                 if (rc2 != DCV_OK) return rc2;
@@ -1944,8 +2071,8 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
     const Item items[] = {
         {"gather<2,2,2,2,S>", (const void*)gather_gemm_kernel<2, 2, 2, 2, true>}, {"gather<2,2,1,4,S>", (const void*)gather_gemm_kernel<2, 2, 1, 4, true>},
         {"gather<1,2,1,4,S>", (const void*)gather_gemm_kernel<1, 2, 1, 4, true>}, {"gather<2,2,2,2,T>", (const void*)gather_gemm_kernel<2, 2, 2, 2, false>},
-        {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, false>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4, false>},
-        {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4, false>}, {"gather_dma_dstep<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, true>},
+        {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, false, false>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4, false, false>},
+        {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4, false, false>}, {"gather_dma_patch<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, false, true>},
         {"thin_gather", (const void*)thin_gather_kernel},
         {"wgrad_dma", (const void*)wgrad_dma_kernel}, {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
         {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, false>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2, false>},

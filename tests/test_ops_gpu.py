@@ -37,6 +37,16 @@ CONVS = [
     ("conv3d_4s122", False, 3, 3, 6, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 2),
     ("conv3d_4s122_wide", False, 3, 36, 40, 4, (1, 2, 2), (0, 1, 1), (5, 4, 4), 2),
     ("conv3d_head", False, 3, 20, 1, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 3),
+    # patch-staged operand (16-byte granules of raw rows): all three tile shapes, ragged last tile, tiny planes
+    ("conv2d_4s2p1_32_oc40", False, 2, 8, 40, 4, 2, 1, (32, 32), 3),
+    ("conv2d_4s2p1_32_oc130", False, 2, 6, 130, 4, 2, 1, (32, 32), 2),
+    ("conv2d_4s2p1_16_oc24", False, 2, 12, 24, 4, 2, 1, (16, 16), 5),
+    ("conv2d_4s2p1_8_oc72", False, 2, 20, 72, 4, 2, 1, (8, 8), 7),
+    ("convT2d_4s2p1_16_oc36", True, 2, 12, 36, 4, 2, 1, (16, 16), 3),
+    ("convT2d_4s2p1_32_oc68", True, 2, 8, 68, 4, 2, 1, (32, 32), 2),
+    ("convT2d_4s2p1_8_oc132", True, 2, 16, 132, 4, 2, 1, (8, 8), 5),
+    ("conv3d_4s122_16_oc70", False, 3, 8, 70, 4, (1, 2, 2), (0, 1, 1), (6, 16, 16), 2),
+    ("conv3d_4s122_32_oc36", False, 3, 8, 36, 4, (1, 2, 2), (0, 1, 1), (5, 32, 32), 2),
 ]
 
 
