@@ -47,6 +47,13 @@ CONVS = [
     ("convT2d_4s2p1_8_oc132", True, 2, 16, 132, 4, 2, 1, (8, 8), 5),
     ("conv3d_4s122_16_oc70", False, 3, 8, 70, 4, (1, 2, 2), (0, 1, 1), (6, 16, 16), 2),
     ("conv3d_4s122_32_oc36", False, 3, 8, 36, 4, (1, 2, 2), (0, 1, 1), (5, 32, 32), 2),
+    # thin patch form (OC <= 4, >= 65536 positions): 3x3 heads, stride-2 stems' data gradients, 3-D depth-step
+    ("convT2d_3s1p1_thin3", True, 2, 12, 3, 3, 1, 1, (64, 64), 16),
+    ("conv2d_3s1p1_from1", False, 2, 1, 8, 3, 1, 1, (64, 64), 17),
+    ("convT2d_4s2p1_to1", True, 2, 8, 1, 4, 2, 1, (32, 32), 65),
+    ("conv2d_4s2p1_head_big", False, 2, 8, 2, 4, 2, 1, (64, 64), 64),
+    ("conv3d_4s122_stem1", False, 3, 1, 8, 4, (1, 2, 2), (0, 1, 1), (9, 64, 64), 8),
+    ("conv3d_4s122_stem3", False, 3, 3, 12, 4, (1, 2, 2), (0, 1, 1), (7, 64, 64), 11),
 ]
 
 
