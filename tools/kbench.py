@@ -5,6 +5,8 @@ import sys
 sys.path.insert(0, '.')
 import torch
 from dcvgan_amd import native as N, ops
+import os as _os
+N.LIB_PATH = _os.environ.get('DCV_LIB', N.LIB_PATH)
 from dcvgan_amd.native import dims5, ptr, stream_ptr, lib
 
 dev = torch.device("cuda:0")
