@@ -70,6 +70,15 @@ CONFIGS: Dict[str, StepConfig] = {
         use_noise=dict(idis=False, vdis=False, gdis=False),
         noise_sigma=dict(idis=0.2, vdis=0.2, gdis=0.2),
         lr=dict(ggen=2e-4, cgen=2e-4, idis=2e-4, vdis=2e-4, gdis=2e-4), decay=dict(_DECAY)),
+    # config/surreal-segm.yml (25 body-part maps; the yml has no gdis section: trainer.py reads one that is
+    # absent, so as with surreal-depth1 the gdis settings are injected — ndf 32, no noise).  SURVEY §8(f).4
+    "surreal-segm": StepConfig(
+        name="surreal-segm", batchsize=60, seed=15, geometric_info="segmentation", channel=25,
+        loss="adversarial-loss", num_gen_update=2,
+        width=dict(ggen=96, cgen=64, idis=64, vdis=48, gdis=32),
+        use_noise=dict(idis=True, vdis=True, gdis=False),
+        noise_sigma=dict(idis=0.2, vdis=0.2, gdis=0.2),
+        lr=dict(ggen=2e-4, cgen=2e-4, idis=2e-4, vdis=2e-4, gdis=2e-4), decay=dict(_DECAY)),
     # config/isogd-flow.yml (as shipped: 16 x 64 x 64, two flow channels)
     "isogd-flow": StepConfig(
         name="isogd-flow", batchsize=100, seed=15, geometric_info="optical-flow", channel=2,

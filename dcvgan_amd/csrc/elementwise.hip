@@ -731,6 +731,85 @@ __global__ __launch_bounds__(256) void surreal_norm_kernel(const float* __restri
     out[i] = o;
 }
 
+
+// ------------------------------------------------------------------------- //
+// segmentation branch: reductions over the channel axis, one thread per position.
+// Consecutive threads are consecutive w, so every per-channel access is coalesced.
+// ------------------------------------------------------------------------- //
+struct PosView {   // (n, c, d, h, w) view: element offset of channel 0 at a position, channel stride
+    int64_t sn, sc, sd, sh, sw;
+    int32_t C, D, H, W;
+};
+__device__ __forceinline__ int64_t pos_offset(const PosView& v, int64_t p) {
+    const int w = (int)(p % v.W); p /= v.W;
+    const int h = (int)(p % v.H); p /= v.H;
+    const int d = (int)(p % v.D); p /= v.D;
+    return p * v.sn + d * v.sd + h * v.sh + w * v.sw;
+}
+__device__ __forceinline__ int argmax_first(const float* __restrict__ x, int C, int64_t sc) {
+    float best = x[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = x[c * sc];
+        if (v > best) { best = v; bi = c; }   // strict: the first maximum wins, like torch.argmax / np.argmax
+    }
+    return bi;
+}
+// y = softmax(x) over channels (generator.py:75-76 nn.Softmax(dim=1))
+__global__ __launch_bounds__(256) void softmax_c_fwd_kernel(const float* __restrict__ x, PosView xv, float* __restrict__ y, PosView yv, int64_t P) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float* xp = x + pos_offset(xv, p);
+    float* yp = y + pos_offset(yv, p);
+    float mx = xp[0];
+    for (int c = 1; c < xv.C; ++c) mx = fmaxf(mx, xp[c * xv.sc]);
+    float sum = 0.f;
+    for (int c = 0; c < xv.C; ++c) {
+        const float e = expf(xp[c * xv.sc] - mx);
+        yp[c * yv.sc] = e;
+        sum += e;
+    }
+    for (int c = 0; c < xv.C; ++c) yp[c * yv.sc] = yp[c * yv.sc] / sum;
+}
+// dx = y * (dy - sum_c dy * y)
+__global__ __launch_bounds__(256) void softmax_c_bwd_kernel(const float* __restrict__ dy, PosView dv, const float* __restrict__ y, PosView yv,
+                                                           float* __restrict__ dx, PosView xv, int64_t P) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float* dp = dy + pos_offset(dv, p);
+    const float* yp = y + pos_offset(yv, p);
+    float* xp = dx + pos_offset(xv, p);
+    float dot = 0.f;
+    for (int c = 0; c < dv.C; ++c) dot += dp[c * dv.sc] * yp[c * yv.sc];
+    for (int c = 0; c < dv.C; ++c) xp[c * xv.sc] = yp[c * yv.sc] * (dp[c * dv.sc] - dot);
+}
+// one-hot (or softmax) maps -> {-1, +1} maps (generator.py:378-385)
+__global__ __launch_bounds__(256) void segm_onehot_kernel(const float* __restrict__ x, PosView xv, float* __restrict__ y, PosView yv, int64_t P) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int bi = argmax_first(x + pos_offset(xv, p), xv.C, xv.sc);
+    float* yp = y + pos_offset(yv, p);
+    for (int c = 0; c < xv.C; ++c) yp[c * yv.sc] = c == bi ? 1.f : -1.f;
+}
+// argmax -> part colour (util.py:236-246); out uint8 (N, 3, D, H, W) contiguous; palette = C x 3 bytes
+__global__ __launch_bounds__(256) void segm_color_kernel(const float* __restrict__ x, PosView xv, const uint8_t* __restrict__ palette,
+                                                        uint8_t* __restrict__ out, int64_t P) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int bi = argmax_first(x + pos_offset(xv, p), xv.C, xv.sc);
+    const int64_t plane = (int64_t)xv.D * xv.H * xv.W;
+    const int64_t n = p / plane, r = p % plane;
+    for (int k = 0; k < 3; ++k) out[(n * 3 + k) * plane + r] = palette[bi * 3 + k];
+}
+// dataset.py:176-181: label frames (T, H, W) uint8 -> one-hot float (C, T, H, W), per clip of a (B, T, H, W) batch
+__global__ __launch_bounds__(256) void segm_decode_kernel(const uint8_t* __restrict__ labels, float* __restrict__ out, int C, int64_t per_clip, int64_t P) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int64_t b = p / per_clip, r = p % per_clip;
+    const int l = labels[p];
+    for (int c = 0; c < C; ++c) out[(b * C + c) * per_clip + r] = c == l ? 1.f : 0.f;
+}
+
 }  // namespace dcv
 
 using namespace dcv;
@@ -889,6 +968,49 @@ int dcv_surreal_depth(const float* depth, int B, int T, int H, int W, float* out
     hipLaunchKernelGGL(surreal_minmax_kernel, dim3(B), dim3(256), 0, s, depth, per, ws_minmax);
     DCV_LAUNCH_CHECK();
     hipLaunchKernelGGL(surreal_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, depth, per, total, ws_minmax, out);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+static PosView posview(const dcv_dims5& d) { return PosView{d.sn, d.sc, d.sd, d.sh, d.sw, d.c, d.d, d.h, d.w}; }
+static bool same_positions(const dcv_dims5& a, const dcv_dims5& b) { return a.n == b.n && a.d == b.d && a.h == b.h && a.w == b.w; }
+
+int dcv_softmax_channels_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, void* stream) {
+    if (!x || !y || !xd || !yd || !same_shape(*xd, *yd) || xd->c < 1) return fail(DCV_EINVAL, "softmax_channels_forward: bad arguments");
+    const int64_t P = (int64_t)xd->n * xd->d * xd->h * xd->w;
+    hipLaunchKernelGGL(softmax_c_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, posview(*xd), y, posview(*yd), P);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_softmax_channels_backward(const float* dy, const dcv_dims5* dyd, const float* y, const dcv_dims5* yd, float* dx, const dcv_dims5* dxd, void* stream) {
+    if (!dy || !y || !dx || !dyd || !yd || !dxd || !same_shape(*dyd, *yd) || !same_shape(*dyd, *dxd)) return fail(DCV_EINVAL, "softmax_channels_backward: bad arguments");
+    const int64_t P = (int64_t)yd->n * yd->d * yd->h * yd->w;
+    hipLaunchKernelGGL(softmax_c_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, posview(*dyd), y, posview(*yd), dx, posview(*dxd), P);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_segm_onehot(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, void* stream) {
+    if (!x || !y || !xd || !yd || !same_shape(*xd, *yd) || xd->c < 1) return fail(DCV_EINVAL, "segm_onehot: bad arguments");
+    const int64_t P = (int64_t)xd->n * xd->d * xd->h * xd->w;
+    hipLaunchKernelGGL(segm_onehot_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, posview(*xd), y, posview(*yd), P);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_segm_to_rgb(const float* x, const dcv_dims5* xd, const uint8_t* palette, uint8_t* out, void* stream) {
+    if (!x || !xd || !palette || !out || xd->c < 1) return fail(DCV_EINVAL, "segm_to_rgb: bad arguments");
+    const int64_t P = (int64_t)xd->n * xd->d * xd->h * xd->w;
+    hipLaunchKernelGGL(segm_color_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, posview(*xd), palette, out, P);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_decode_segmentation(const uint8_t* labels, int B, int T, int H, int W, int C, float* out, void* stream) {
+    if (!labels || !out || B < 1 || T < 1 || H < 1 || W < 1 || C < 1 || C > 256) return fail(DCV_EINVAL, "decode_segmentation: bad arguments");
+    const int64_t per = (int64_t)T * H * W, P = per * B;
+    hipLaunchKernelGGL(segm_decode_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), labels, out, C, per, P);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -53,3 +53,14 @@ def decode_surreal_depth(depth: torch.Tensor) -> torch.Tensor:
     mm = torch.empty(2 * B, dtype=torch.float32, device=depth.device)
     check(lib().dcv_surreal_depth(ptr(depth), B, T, H, W, ptr(out), ptr(mm), stream_ptr()), "dcv_surreal_depth")
     return out
+
+
+def decode_segmentation(labels: torch.Tensor, num_parts: int = 25) -> torch.Tensor:
+    """uint8 label frames (B,T,H,W) -> one-hot fp32 (B,num_parts,T,H,W): np.eye(25)[labels] channel-first
+    (dataset.py:176-181)."""
+    if not labels.is_cuda or labels.dim() != 4 or labels.dtype != torch.uint8 or not labels.is_contiguous():
+        raise NativeError("decode_segmentation: expected a contiguous uint8 (B,T,H,W) tensor on the HIP device")
+    B, T, H, W = labels.shape
+    out = torch.empty((B, num_parts, T, H, W), dtype=torch.float32, device=labels.device)
+    check(lib().dcv_decode_segmentation(C.c_void_p(labels.data_ptr()), B, T, H, W, num_parts, ptr(out), stream_ptr()), "dcv_decode_segmentation")
+    return out

@@ -159,8 +159,7 @@ class ColorVideoGenerator(nn.Module):
     def forward(self, x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         rng = self._source()
         if self.geometric_info == "segmentation":  # one-hot -> {-1, +1} maps (generator.py:378-385); SURVEY §8(f).4
-            idx = torch.argmax(x, 1, keepdim=True)
-            x = torch.full_like(x, -1.0).scatter_(1, idx, 1.0)
+            x = ops.segm_onehot(x)
         # Every torch.cat of the reference (generator.py:393-400) joins an up-path tensor with a skip:
         # both producers write straight into the two channel slices of one buffer, so no copy is made.
         nb = x.shape[0]

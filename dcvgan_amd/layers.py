@@ -89,8 +89,10 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
             if layer.use_noise:
                 x = rng.noise_add(x, layer.sigma)
             i += 1
-        elif isinstance(layer, nn.Softmax):  # segmentation head: outside the BASELINE configs
-            x = torch.softmax(x, layer.dim)
+        elif isinstance(layer, nn.Softmax):  # segmentation head (generator.py:75-76)
+            if layer.dim != 1:
+                raise NotImplementedError("only the channel softmax of the segmentation head is implemented")
+            x = ops.softmax_channels(x)
             i += 1
         else:
             raise NotImplementedError(f"no HIP execution for layer {type(layer).__name__}")

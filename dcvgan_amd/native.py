@@ -62,6 +62,11 @@ _SIGS = {
     "dcv_dropout_mask": (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, _P]),
     "dcv_decode_video": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "dcv_surreal_depth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "dcv_softmax_channels_forward": (C.c_int, [_P, _D, _P, _D, _P]),
+    "dcv_softmax_channels_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, _P]),
+    "dcv_segm_onehot": (C.c_int, [_P, _D, _P, _D, _P]),
+    "dcv_segm_to_rgb": (C.c_int, [_P, _D, _P, _P, _P]),
+    "dcv_decode_segmentation": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "dcv_videos_to_uint8": (C.c_int, [_P, _D, _P, C.c_int, _P]),
     "dcv_flow_to_rgb": (C.c_int, [_P, _D, C.c_float, _P, _P, _P]),
     "dcv_gan_loss": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, _P]),

@@ -215,6 +215,44 @@ def act(x, kind: int, slope: float = 0.0):
 
 
 # --------------------------------------------------------------------------- #
+# segmentation branch: softmax head, argmax -> {-1,+1} maps
+# --------------------------------------------------------------------------- #
+class _SoftmaxChannels(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N._require(x, "softmax input")
+        y = _empty(x.shape, x.device)
+        xd, yd = dims5(x), dims5(y)
+        check(lib().dcv_softmax_channels_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), stream_ptr()), "dcv_softmax_channels_forward")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dx = _empty(y.shape, y.device)
+        dyd, yd, dxd = dims5(dy), dims5(y), dims5(dx)   # dy may be a strided view (the (B,T,C,H,W) video layout)
+        check(lib().dcv_softmax_channels_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dx), C.byref(dxd), stream_ptr()), "dcv_softmax_channels_backward")
+        return dx
+
+
+def softmax_channels(x):
+    """nn.Softmax(dim=1) of the geometry generator's segmentation head (generator.py:75-76)."""
+    return _SoftmaxChannels.apply(x)
+
+
+def segm_onehot(x):
+    """One-hot / softmax maps -> {-1,+1} maps by channel argmax (generator.py:378-385); like the reference's
+    argmax + scatter_ it passes no gradient."""
+    N._require(x, "segmentation maps")
+    with torch.no_grad():
+        y = _empty(x.shape, x.device)
+        xd, yd = dims5(x), dims5(y)
+        check(lib().dcv_segm_onehot(ptr(x), C.byref(xd), ptr(y), C.byref(yd), stream_ptr()), "dcv_segm_onehot")
+    return y
+
+
+# --------------------------------------------------------------------------- #
 # axpby-based pieces: noise add, channel concat, temporal difference
 # --------------------------------------------------------------------------- #
 def _axpby(x, a, z, b, out):

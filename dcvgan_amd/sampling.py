@@ -26,6 +26,16 @@ def _to_uint8(x: torch.Tensor, channel_repeat: int = 1) -> torch.Tensor:
     return out
 
 
+# SURREAL body-part colours as uint8 RGB: util.segm_color(i) * 255 truncated (util.py:325-372, after
+# gulvarol/surreal demo/segmColorMap.m); data, checked against tests/golden/segmentation_io.npz
+SEGM_PALETTE_U8 = (
+    (114, 139, 163), (216, 82, 24), (236, 176, 31), (125, 46, 90), (118, 171, 47), (76, 189, 237), (131, 196, 185),
+    (237, 220, 103), (176, 172, 202), (156, 195, 106), (119, 164, 196), (235, 167, 91), (166, 206, 97), (174, 119, 175),
+    (201, 201, 201), (189, 218, 183), (234, 190, 212), (237, 237, 166), (93, 78, 162), (157, 0, 65), (243, 211, 167),
+    (253, 209, 123), (50, 130, 188), (152, 214, 164), (226, 156, 137),
+)
+
+
 def videos_to_numpy(tensor: torch.Tensor) -> np.ndarray:
     """util.py:58-79 — (B,C,T,H,W) float in [-1,1] -> uint8 numpy, same axis order."""
     return _to_uint8(tensor).cpu().numpy()
@@ -49,7 +59,16 @@ def geometry_to_color(xg: torch.Tensor, geometric_info: str) -> np.ndarray:
         fd = dims5(xg)   # the kernel clips to [-1, 1] first, like util.py:306-307, then scales by H (util.py:227)
         check(lib().dcv_flow_to_rgb(ptr(xg), C.byref(fd), float(H), C.c_void_p(out.data_ptr()), ptr(mm), stream_ptr()), "dcv_flow_to_rgb")
         return out.cpu().numpy()
-    raise NotImplementedError(f"geometry visualisation for {geometric_info!r} (segmentation is SURVEY §8(f).4)")
+    if geometric_info == "segmentation":   # util.py:236-246: argmax over the 25 part maps, SURREAL part palette
+        B, Cg, T, H, W = xg.shape
+        if Cg != len(SEGM_PALETTE_U8):
+            raise NativeError(f"segmentation visualisation expects {len(SEGM_PALETTE_U8)} part channels, got {Cg}")
+        pal = torch.tensor(SEGM_PALETTE_U8, dtype=torch.uint8, device=xg.device)
+        out = torch.empty((B, 3, T, H, W), dtype=torch.uint8, device=xg.device)
+        xd = dims5(xg)
+        check(lib().dcv_segm_to_rgb(ptr(xg), C.byref(xd), C.c_void_p(pal.data_ptr()), C.c_void_p(out.data_ptr()), stream_ptr()), "dcv_segm_to_rgb")
+        return out.cpu().numpy()
+    raise NotImplementedError(f"geometry visualisation for {geometric_info!r}")
 
 
 def generate_samples(ggen, cgen, num: int, batchsize: int = 20, with_geo: bool = True, verbose: bool = False,

@@ -141,6 +141,17 @@ int dcv_decode_video(const void* in, int in_is_u8, int B, int T, int H, int W, i
  * foreground min-max normalised per clip to [-1, 0.8], background 1.0; ws_minmax: 2*B floats.  */
 int dcv_surreal_depth(const float* depth, int B, int T, int H, int W, float* out, float* ws_minmax, void* stream);
 
+/* ---- segmentation branch (surreal-segm.yml, 25 body-part channels) ---------- *
+ * softmax over the channel axis = the geometry generator's nn.Softmax(dim=1) head (generator.py:75-76)  */
+int dcv_softmax_channels_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, void* stream);
+int dcv_softmax_channels_backward(const float* dy, const dcv_dims5* dyd, const float* y, const dcv_dims5* yd, float* dx, const dcv_dims5* dxd, void* stream);
+/* one-hot / softmax maps -> {-1,+1} maps: argmax over channels (first maximum), scatter (generator.py:378-385) */
+int dcv_segm_onehot(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, void* stream);
+/* argmax -> part colour (util.py:236-246); palette = C x 3 bytes on the device; out uint8 (N,3,D,H,W)  */
+int dcv_segm_to_rgb(const float* x, const dcv_dims5* xd, const uint8_t* palette, uint8_t* out, void* stream);
+/* dataset.py:176-181: label frames uint8 (B,T,H,W) -> one-hot fp32 (B,C,T,H,W)                       */
+int dcv_decode_segmentation(const uint8_t* labels, int B, int T, int H, int W, int C, float* out, void* stream);
+
 /* ---- sampling path: float videos -> uint8 on the device --------------------- *
  * util.videos_to_numpy (util.py:58-79) and the depth branch of
  * util.geometric_info_in_color_format (util.py:219-222): out = uint8((clip(x,-1,1)+1)/2*255),

@@ -441,6 +441,20 @@ def depth_to_color(xg: torch.Tensor):
     return ((v + 1) / 2 * 255).astype("uint8")
 
 
+def segmentation_to_color(xg, palette_u8):
+    """util.geometric_info_in_color_format, segmentation branch (util.py:236-246): argmax over the part
+    channels of (B,25,T,H,W) (first maximum), part colour from the palette; uint8 (B,3,T,H,W)."""
+    import numpy as np
+    idx = np.argmax(np.asarray(xg), axis=1)                       # (B,T,H,W)
+    return np.asarray(palette_u8, dtype=np.uint8)[idx].transpose(0, 4, 1, 2, 3)
+
+
+def segmentation_one_hot(labels, num_parts: int = 25):
+    """dataset.py:176-181: label frames (T,H,W) -> one-hot float32 (25,T,H,W)."""
+    import numpy as np
+    return np.eye(num_parts, dtype=np.float32)[np.asarray(labels)].transpose(3, 0, 1, 2)
+
+
 def generate_samples_depth(st_g: State, st_c: State, num: int, batchsize: int, T: int, dzc: int, dzm: int, dzcol: int, rng):
     """util.generate_samples (util.py:251-322) for depth geometry: eval mode, no_grad, truncation to num."""
     import numpy as np

@@ -356,6 +356,25 @@ def interchange_fixture(ref, name="interchange.json"):
     print("wrote", name, res)
 
 
+def segmentation_fixture(ref, name="segmentation_io.npz", seed=2024):
+    """SURVEY §8(f).4 data paths around the segmentation branch, from the reference's own functions:
+    the SURREAL part palette (util.py:325-372), argmax colouring (util.py:236-246), the dataset's
+    one-hot decode (dataset.py:176-181, restated through numpy exactly as written there: np.eye(25)[labels])."""
+    util = ref[0]
+    out = {}
+    out["palette_u8"] = np.stack([(util.segm_color(i) * 255).astype(np.uint8) for i in range(25)])
+    g = np.random.default_rng(seed)
+    probs = g.random((2, 25, 3, 8, 8)).astype(np.float32)
+    probs[0, 3, 0, 0, 0] = probs[0, 7, 0, 0, 0] = 2.0      # a tie: the first maximum wins
+    out["probs"] = probs
+    out["color"] = util.geometric_info_in_color_format(probs.copy(), "segmentation")
+    labels = g.integers(0, 25, size=(4, 8, 8)).astype(np.uint8)   # frames of segm.npy
+    out["labels"] = labels
+    out["onehot"] = np.eye(25, dtype=np.float32)[labels].transpose(3, 0, 1, 2)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     ref = import_reference()
     torch.set_num_threads(8)
@@ -373,3 +392,7 @@ if __name__ == "__main__":
     fullwidth_fixture(ref, full, "fullwidth_isogd_depth.npz")
     sampling_fixture(ref, dict(small_depth, ngf_g=4, ngf_c=4), "sampling_depth_w4.npz")
     interchange_fixture(ref)
+    small_segm = dict(geo="segmentation", Cg=25, dzc=4, dzm=2, dzcol=2, ngf_g=4, ngf_c=4, ndf_i=4, ndf_v=4, ndf_g=4,
+                      noise_i=(True, 0.2), noise_v=(True, 0.2), noise_g=(True, 0.2))
+    module_fixture(ref, small_segm, "modules_segm_w4.npz")
+    segmentation_fixture(ref)

@@ -37,14 +37,14 @@ def share_rng(models, log):
     return r
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_generators_train(dev, fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx); B = cfg.batchsize
     st = G.states(fx)
     torch.manual_seed(int(fx["meta/seed_gen_train"]))
     rng = O.TorchRng()
-    xg_o = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, True)
-    xc_o = O.cgen_forward_videos(st["cgen"], xg_o, cfg.dim_z_color, rng, True)
+    xg_o = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, True, segmentation=cfg.geometric_info == 'segmentation')
+    xc_o = O.cgen_forward_videos(st["cgen"], xg_o, cfg.dim_z_color, rng, True, segmentation=cfg.geometric_info == 'segmentation')
     models = hip_models(fx, cfg, dev)
     r = share_rng(models, rng.log)
     from dcvgan_amd import native
@@ -59,16 +59,20 @@ def test_generators_train(dev, fixture):
     cot_g = torch.cos(torch.arange(xg.numel(), dtype=torch.float32) * 0.37).view(xg.shape).to(dev)
     cot_c = torch.sin(torch.arange(xc.numel(), dtype=torch.float32) * 0.11).view(xc.shape).to(dev)
     ((xg * cot_g).sum() + (xc * cot_c).sum()).backward()
+    # segmentation: cgen sees exact {-1,+1} maps, so at width 4 a whole plane of pre-activations sits on a few
+    # discrete values and single (Leaky)ReLU kink flips move the 4-element BN gradients by ~1e-3 (measured
+    # 1.02e-3 on down_blocks.0 gamma; the oracle on CPU hits the fixture to 1e-5): 3e-3 there, 1e-3 elsewhere
+    gtol = 3e-3 if cfg.geometric_info == "segmentation" else TOL
     for n in ("ggen", "cgen"):
         for k, p in models[n].named_parameters():
-            assert G.relerr(p.grad.cpu().numpy(), fx[f"gen_train/grad/{n}/{k}"]) < TOL, (n, k)
+            assert G.relerr(p.grad.cpu().numpy(), fx[f"gen_train/grad/{n}/{k}"]) < gtol, (n, k)
         for k, v in models[n].state_dict().items():
             key = f"gen_train/after/{n}/{k}"
             if key in fx:
                 assert np.allclose(v.cpu().numpy(), fx[key], rtol=1e-4, atol=1e-6), key
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_generators_eval(dev, fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx); B = cfg.batchsize
     st = G.states(fx)
@@ -80,15 +84,26 @@ def test_generators_eval(dev, fixture):
     torch.manual_seed(int(fx["meta/seed_gen_eval"]))
     rng = O.TorchRng()
     with torch.no_grad():
-        xg_o = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, False)
-        O.cgen_forward_videos(st["cgen"], xg_o, cfg.dim_z_color, rng, False)
+        xg_o = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, False, segmentation=cfg.geometric_info == 'segmentation')
+        O.cgen_forward_videos(st["cgen"], xg_o, cfg.dim_z_color, rng, False, segmentation=cfg.geometric_info == 'segmentation')
     from dcvgan_amd import trainer
     models = trainer.build_models(cfg, dev)
     for n in ("ggen", "cgen"):
         models[n].load_state_dict({k: v.clone() for k, v in st[n].items()}); models[n].to(dev).eval()
     share_rng(models, rng.log)
     with torch.no_grad():
-        xg = models["ggen"].sample_videos(B); xc = models["cgen"].forward_videos(xg)
+        xg = models["ggen"].sample_videos(B)
+        if cfg.geometric_info == "segmentation":
+            # cgen starts with an argmax over the 25 part maps (generator.py:381): where the reference's two
+            # largest probabilities are within an ulp (or exactly tied) the 3e-8 difference between the HIP and
+            # CPU softmax picks the other part — a discontinuity of the model, not a kernel error.  Check that
+            # flips happen only there, then colourise the reference's own maps so the rest of cgen is compared.
+            top2 = xg_o.topk(2, dim=1).values
+            flips = xg.cpu().argmax(1) != xg_o.argmax(1)
+            assert int(flips.sum()) < 1e-3 * flips.numel() and float((top2[:, 0] - top2[:, 1])[flips].max() if flips.any() else 0.0) < 1e-6
+            xc = models["cgen"].forward_videos(xg_o.to(dev))
+        else:
+            xc = models["cgen"].forward_videos(xg)
     assert G.relerr(G.sub(xg), fx["gen_eval/xg_sub"]) < TOL and G.relerr(G.sub(xc), fx["gen_eval/xc_sub"]) < TOL
 
 
@@ -125,7 +140,7 @@ def _dis_conditioning(fx, cfg, xg_c, xc_c, t):
     return cond
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_discriminators(dev, fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx); B = cfg.batchsize
     st = G.states(fx)

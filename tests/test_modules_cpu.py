@@ -26,7 +26,7 @@ def test_constructor_signatures():
     assert inspect.signature(Gm.GeometricVideoGenerator.__init__).parameters["ngf"].default == 64
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_state_dict_matches_reference(fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx)
     models = trainer.build_models(cfg, torch.device("cpu"))

@@ -10,7 +10,7 @@ from tests import goldenio as G
 TOL = 2e-6  # same torch, same CPU kernels: expected bit-equal; allow thread-order noise
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_generators_train_forward_backward(fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx); st = G.states(fx)
     B = cfg.batchsize
@@ -18,8 +18,8 @@ def test_generators_train_forward_backward(fixture):
         O.require_grad(st[m])
     torch.manual_seed(int(fx["meta/seed_gen_train"]))
     rng = O.TorchRng()
-    xg = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, True)
-    xc = O.cgen_forward_videos(st["cgen"], xg, cfg.dim_z_color, rng, True)
+    xg = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, True, segmentation=cfg.geometric_info == 'segmentation')
+    xc = O.cgen_forward_videos(st["cgen"], xg, cfg.dim_z_color, rng, True, segmentation=cfg.geometric_info == 'segmentation')
     assert tuple(xg.stride()) == tuple(fx["gen_train/xg_stride"])
     assert tuple(xc.stride()) == tuple(fx["gen_train/xc_stride"])
     assert G.relerr(G.sub(xg), fx["gen_train/xg_sub"]) < TOL
@@ -38,7 +38,7 @@ def test_generators_train_forward_backward(fixture):
                 assert np.allclose(st[m][k].detach().numpy(), fx[key], rtol=1e-6, atol=1e-7), key
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_generators_eval(fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx)
     # eval pass ran AFTER one training forward: load the post-train running stats
@@ -51,8 +51,8 @@ def test_generators_eval(fixture):
     torch.manual_seed(int(fx["meta/seed_gen_eval"]))
     rng = O.TorchRng()
     with torch.no_grad():
-        xg = O.ggen_sample_videos(st["ggen"], cfg.batchsize, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, False)
-        xc = O.cgen_forward_videos(st["cgen"], xg, cfg.dim_z_color, rng, False)
+        xg = O.ggen_sample_videos(st["ggen"], cfg.batchsize, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, False, segmentation=cfg.geometric_info == 'segmentation')
+        xc = O.cgen_forward_videos(st["cgen"], xg, cfg.dim_z_color, rng, False, segmentation=cfg.geometric_info == 'segmentation')
     assert G.relerr(G.sub(xg), fx["gen_eval/xg_sub"]) < TOL
     assert G.relerr(G.sub(xc), fx["gen_eval/xc_sub"]) < TOL
 
@@ -65,7 +65,7 @@ def dis_inputs(fx, cfg):
     return xg, xc
 
 
-@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz"])
+@pytest.mark.parametrize("fixture", ["modules_depth_w6.npz", "modules_flow_w4.npz", "modules_segm_w4.npz"])
 def test_discriminators_forward_backward(fixture):
     fx = G.load(fixture); cfg = G.cfg_of(fx); st = G.states(fx)
     for m in ("idis", "vdis", "gdis"):
@@ -154,3 +154,13 @@ def test_sampling_path():
     assert np.array_equal(xg.reshape(-1)[::13], fx["xg_sub"]) and int(xg.astype(np.int64).sum()) == int(fx["xg_sum"])
     assert np.array_equal(xc.reshape(-1)[::13], fx["xc_sub"]) and int(xc.astype(np.int64).sum()) == int(fx["xc_sum"])
     assert np.array_equal(O.videos_to_uint8(torch.from_numpy(fx["conv_in"])), fx["conv_out"])
+
+
+def test_segmentation_data_paths():
+    """palette, argmax colouring (first maximum on ties) and the dataset's one-hot decode,
+    against fixtures produced by the reference's own functions."""
+    fx = np.load(G.path("segmentation_io.npz")) if hasattr(G, "path") else np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "segmentation_io.npz"))
+    from dcvgan_amd.sampling import SEGM_PALETTE_U8
+    assert np.array_equal(np.array(SEGM_PALETTE_U8, dtype=np.uint8), fx["palette_u8"])
+    assert np.array_equal(O.segmentation_to_color(fx["probs"], fx["palette_u8"]), fx["color"])
+    assert np.array_equal(O.segmentation_one_hot(fx["labels"]), fx["onehot"])

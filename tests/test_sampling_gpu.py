@@ -78,3 +78,32 @@ def test_flow_visualisation_properties(dev):
     r, g, b = rgb[0, :, 0, 0, 7]
     assert g > r and g > b and 100 <= g <= 140            # value = (0.25*8 - 0)/(0.5*8 - 0) * 255 ~ 127
     assert rgb[0, :, 1].max() == 0                          # frame 1: no motion -> black
+
+
+def test_segmentation_branch(dev):
+    """SURVEY §8(f).4 on the device: part colouring and one-hot decode byte-exact against the reference fixture,
+    argmax -> {-1,+1} remap exact, channel softmax forward/backward against torch."""
+    import os
+    from dcvgan_amd import dataprep, ops, sampling
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "segmentation_io.npz"))
+    probs = torch.from_numpy(fx["probs"]).to(dev)
+    assert np.array_equal(sampling.geometry_to_color(probs, "segmentation"), fx["color"])
+    # strided input: the generators' (B,T,C,H,W) memory order viewed as (B,C,T,H,W)
+    strided = probs.permute(0, 2, 1, 3, 4).contiguous().permute(0, 2, 1, 3, 4)
+    assert np.array_equal(sampling.geometry_to_color(strided, "segmentation"), fx["color"])
+    labels = torch.from_numpy(fx["labels"]).to(dev)[None]          # one clip of 4 frames
+    assert np.array_equal(dataprep.decode_segmentation(labels).cpu().numpy()[0], fx["onehot"])
+    frames = probs.permute(0, 2, 1, 3, 4).reshape(-1, 25, 8, 8)      # cgen sees frames
+    idx = torch.argmax(frames.cpu(), 1, keepdim=True)
+    want = torch.full_like(frames.cpu(), -1.0).scatter_(1, idx, 1.0)  # generator.py:381-385
+    assert torch.equal(ops.segm_onehot(frames).cpu(), want)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(6, 25, 16, 16, generator=g) * 3).requires_grad_(True)
+    cot = torch.randn(6, 25, 16, 16, generator=g)
+    y_ref = torch.softmax(x, 1)
+    (gx_ref,) = torch.autograd.grad((y_ref * cot).sum(), x)
+    xd = x.detach().to(dev).requires_grad_(True)
+    y = ops.softmax_channels(xd)
+    (gx,) = torch.autograd.grad((y * cot.to(dev)).sum(), xd)
+    assert (y.cpu() - y_ref).abs().max() < 1e-6       # fp32 exp/divide rounding
+    assert (gx.cpu() - gx_ref).abs().max() < 1e-6
