@@ -84,21 +84,25 @@ class DataParallelAdam:
         versions = tuple((id(g), g._version) for g in grads)
         if self.world == 1 or versions == self._reduced_versions:
             return
-        # one flat bucket per <= bucket_bytes: xGMI rings are per-link bound, so few large messages
+        # one flat bucket per <= bucket_bytes: xGMI rings are per-link bound, so few large messages.  The
+        # reduced bucket is not copied back: each parameter's .grad becomes a view into it (one cat kernel
+        # and one collective per bucket instead of a copy kernel per parameter).
+        owners = [p for p in self.inner.params if p.grad is not None]
         bucket, size = [], 0
-        for g in grads + [None]:
-            if g is None or (size + g.numel() * 4 > self.bucket_bytes and bucket):
-                flat = torch.cat([b.reshape(-1) for b in bucket])
+        for p in owners + [None]:
+            if p is None or (size + p.grad.numel() * 4 > self.bucket_bytes and bucket):
+                flat = torch.cat([b.grad.reshape(-1) for b in bucket])
                 self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
                 off = 0
                 for b in bucket:
-                    b.copy_(flat[off:off + b.numel()].view_as(b))
-                    off += b.numel()
+                    n = b.grad.numel()
+                    b.grad = flat[off:off + n].view(b.grad.shape)
+                    off += n
                 bucket, size = [], 0
-            if g is not None:
-                bucket.append(g)
-                size += g.numel() * 4
-        self._reduced_versions = tuple((id(g), g._version) for g in grads)
+            if p is not None:
+                bucket.append(p)
+                size += p.grad.numel() * 4
+        self._reduced_versions = tuple((id(g), g._version) for g in self._grads())
 
     def step(self):
         self.reduce_gradients()
