@@ -47,6 +47,10 @@ CONVS = [
     ("convT2d_4s2p1_8_oc132", True, 2, 16, 132, 4, 2, 1, (8, 8), 5),
     ("conv3d_4s122_16_oc70", False, 3, 8, 70, 4, (1, 2, 2), (0, 1, 1), (6, 16, 16), 2),
     ("conv3d_4s122_32_oc36", False, 3, 8, 36, 4, (1, 2, 2), (0, 1, 1), (5, 32, 32), 2),
+    # LDS-DMA weight-gradient kernel (128-channel tiles), dense operand staged in 16-byte granules
+    ("conv2d_4s2p1_wgrad_dma", False, 2, 16, 128, 4, 2, 1, (16, 16), 9),
+    ("convT2d_4s2p1_wgrad_dma", True, 2, 128, 8, 4, 2, 1, (8, 8), 21),
+    ("conv3d_4s122_wgrad_dma", False, 3, 8, 128, 4, (1, 2, 2), (0, 1, 1), (6, 16, 16), 3),
     # thin patch form (OC <= 4, >= 65536 positions): 3x3 heads, stride-2 stems' data gradients, 3-D depth-step
     ("convT2d_3s1p1_thin3", True, 2, 12, 3, 3, 1, 1, (64, 64), 16),
     ("conv2d_3s1p1_from1", False, 2, 1, 8, 3, 1, 1, (64, 64), 17),
