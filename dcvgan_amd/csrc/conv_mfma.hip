@@ -28,6 +28,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace dcv {
@@ -94,6 +95,10 @@ struct GatherArgs {
     int32_t p_log2ow, p_iwp, p_ihmin, p_iwmin4;
     int32_t p_dw1, p_sc4, p_pad1, p_pad2;     // word step from an even k row to the next (tap uw -> uw + 1); channel stride in bytes
     FastDiv p_gpr;                            // granules per patch row = IW / 4 + 2
+    // BatchNorm statistics of the output, fused into the epilogue: stat[(class * stat_ntm + m tile)][OCp][2] =
+    // {sum, sum of squares} over the tile's positions (fp32, <= 256 terms each; combined in fp64 by the BN op)
+    float* stat;
+    int32_t stat_ntm, stat_cls;
 };
 
 // up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
@@ -431,6 +436,53 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
 // the out-of-range voffset.  Per step: wait own DMAs + barrier, issue next tile's DMAs into the
 // other buffer, 32 MFMAs per wave on this one.
 // --------------------------------------------------------------------------- //
+// Per-tile BatchNorm partial sums from the accumulators (positions past M hold exact zeros: their operand
+// rows were padding).  Rows of one wave are reduced over its 32-lane halves with xor-shuffles, the WM waves
+// that share an output-channel row meet in LDS and are added in a fixed order.
+// Sum over each 32-lane half of the wave, valid in lanes 16-31 / 48-63: five DPP adds (quad swaps, half-row and
+// row mirrors, then lane 15 of the even rows broadcast into the odd rows) instead of five LDS-crossbar shuffles.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    auto dpp = [](float x, auto ctrl, auto rows) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rows)::value, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+template <int TOC, int TM, int WOC, int WM>
+__device__ __forceinline__ void tile_bn_partials(const GatherArgs& a, const f32x16 (&acc)[TOC][TM], float* smem, int tid, int lane, int woc, int wm, int oc0, int m_t) {
+    constexpr int BN = 32 * TOC * WOC;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    __syncthreads();   // every wave has left the K loop: the tile buffers are free
+#pragma unroll
+    for (int i = 0; i < TOC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+            s1 = half_wave_sum(s1);
+            s2 = half_wave_sum(s2);
+            if (l31 == 31) {
+                const int ocl = (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                smem[(wm * BN + ocl) * 2] = s1;
+                smem[(wm * BN + ocl) * 2 + 1] = s2;
+            }
+        }
+    __syncthreads();
+    float* __restrict__ dst = a.stat + ((int64_t)(a.stat_cls * a.stat_ntm + m_t) * a.OCp + oc0) * 2;
+    for (int e = tid; e < 2 * BN; e += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) t += smem[w * BN * 2 + e];
+        dst[e] = t;
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 
 // DSTEP (structured == 2): a K step is (4 channels, ONE depth tap, 2x2 inner taps) — the 3-D discriminators'
@@ -743,6 +795,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         return;
     }
     gather_epilogue<TOC, TM>(a, acc, m0, wm * TM * 32, l31, lhi, oc0 + woc * TOC * 32, n0);
+    if (a.stat) tile_bn_partials<TOC, TM, WOC, WM>(a, acc, smem, tid, lane, woc, wm, oc0, m_t);
     DCV_STAMP_OUT()
 }
 
@@ -1490,9 +1543,25 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
 static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_dims5& yd, const float* w,
                       int RC, int OC, int64_t ws_o, int64_t ws_r, int KH, int KW,
                       const std::vector<GatherClass>& classes, int act, float slope, int accumulate,
-                      void* ws, size_t ws_bytes, hipStream_t stream, const char* tag) {
+                      void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
+                      float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr) {
     const TileCfg tc = pick_gather_tile(OC);
     const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
+    // fused BatchNorm partial sums (forward only): one row of {sum, sum^2} per (class, position tile)
+    int stat_ntm = 0, stat_ncls = 0, stat_ci = 0;
+    bool stat_ok = stat != nullptr && act == DCV_ACT_NONE && !accumulate && tc.bn != 4;
+    if (stat_ok) {
+        for (const GatherClass& c : classes) {
+            if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+            const int64_t Mc = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+            stat_ntm = std::max<int>(stat_ntm, (int)((Mc + tc.bm - 1) / tc.bm));
+            ++stat_ncls;
+        }
+        const size_t need = (size_t)stat_ncls * stat_ntm * OCp * 2 * sizeof(float);
+        if (need == 0 || need > stat_bytes) stat_ok = false;
+        else DCV_HIP_CHECK(hipMemsetAsync(stat, 0, need, stream));
+    }
+    if (stat_parts) *stat_parts = 0;
     size_t ws_off = 0;
     GatherArgsPack pend;
     PackArgs packs;
@@ -1648,6 +1717,9 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.slab = slab;
         a.kper = kper;
         a.Mp = Mp;
+        a.stat = stat_ok ? stat : nullptr;
+        a.stat_ntm = stat_ntm;
+        a.stat_cls = stat_ci++;
         bool thin_struct = false;
         if (tc.bn == 4 && (T == 4 || T == 9 || T == 16) && xd.sc * 4 < (1ll << 30) && (KS2 == 1 || (kper * 16) % T == 0)) {
             // K order is (rc, ud, uh, uw): tap t of every channel has the same relative offset
@@ -1753,6 +1825,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         const bool dma = a.structured && tc.bn != 4 && getenv("DCV_NO_LDS_DMA") == nullptr;
+        if (!dma || KS2 > 1) stat_ok = false;   // only the LDS-DMA kernel's direct epilogue produces the sums
         if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
             int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
             if (rcp != DCV_OK) return rcp;
@@ -1805,6 +1878,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         int rc2 = flush_pending(pend, npend, pend_grid, tc, KSpend, OCpend, stream);
         if (rc2 != DCV_OK) return rc2;
     }
+    if (stat_parts && stat_ok) *stat_parts = stat_ncls * stat_ntm;
     return DCV_OK;
 }
 
@@ -2108,7 +2182,8 @@ uint64_t dcv_launch_count(void) { return g_launches.load(); }
 // which: 0 forward, 1 backward-data, 2 backward-weight
 static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, const dcv_dims5* xd, const float* w,
                          float* out, const dcv_dims5* yd, int act, float slope, int accumulate,
-                         void* ws, size_t ws_bytes, void* stream, size_t* need_only) {
+                         void* ws, size_t ws_bytes, void* stream, size_t* need_only,
+                         float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr) {
     // xd = module input dims, yd = module output dims, always.
     int rc = check_geom(g, xd, yd, "conv");
     if (rc != DCV_OK) return rc;
@@ -2142,13 +2217,26 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
             ws_o = T;
             ws_r = (int64_t)OC * T;
         }
+        if (stat_need) {   // upper bound of the fused-BN partial-sum buffer
+            const TileCfg tc = pick_gather_tile(OC);
+            const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
+            int64_t ntm = 0, ncls = 0;
+            for (const GatherClass& c : cls) {
+                const int64_t Mc = (int64_t)dst.n * std::max(c.o_ext[0], 0) * std::max(c.o_ext[1], 0) * std::max(c.o_ext[2], 0);
+                ntm = std::max<int64_t>(ntm, (Mc + tc.bm - 1) / tc.bm);
+                ++ncls;
+            }
+            *stat_need = (size_t)(ncls * ntm * OCp * 2) * sizeof(float);
+            return DCV_OK;
+        }
         if (need_only) {
             *need_only = gather_ws_bytes(RC, OC, dst.n, cls);
             return DCV_OK;
         }
         if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
         return run_gather(a_, src, out, dst, w, RC, OC, ws_o, ws_r, k[1], k[2], cls, act, slope, accumulate, ws, ws_bytes, st,
-                          which == 0 ? (g->transposed ? "convT_fwd" : "conv_fwd") : (g->transposed ? "convT_bwd_data" : "conv_bwd_data"));
+                          which == 0 ? (g->transposed ? "convT_fwd" : "conv_fwd") : (g->transposed ? "convT_bwd_data" : "conv_bwd_data"),
+                          stat, stat_bytes, stat_parts);
     }
     return fail(DCV_EINVAL, "conv: bad dispatch");
 }
@@ -2170,6 +2258,20 @@ size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, cons
 int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
                      int act, float slope, void* ws, size_t ws_bytes, void* stream) {
     return conv_dispatch(0, g, x, xd, w, y, yd, act, slope, 0, ws, ws_bytes, stream, nullptr);
+}
+
+size_t dcv_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y) {
+    size_t need = 0;
+    if (conv_dispatch(0, g, nullptr, x, nullptr, nullptr, y, 0, 0.f, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, &need) != DCV_OK) return 0;
+    return need;
+}
+
+int dcv_conv_forward_stats(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
+                           float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream) {
+    if (!stat || !nparts || !pitch) return fail(DCV_EINVAL, "conv_forward_stats: null pointer");
+    const TileCfg tc = pick_gather_tile(yd ? yd->c : 1);
+    *pitch = yd ? (yd->c + tc.bn - 1) / tc.bn * tc.bn : 0;
+    return conv_dispatch(0, g, x, xd, w, y, yd, DCV_ACT_NONE, 0.f, 0, ws, ws_bytes, stream, nullptr, stat, stat_bytes, nparts);
 }
 
 int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd,

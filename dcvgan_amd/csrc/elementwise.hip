@@ -328,6 +328,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(ChanMap m, const float* _
     if (threadIdx.x == 0) { partial[(int64_t)blockIdx.x * 2] = acc[0]; partial[(int64_t)blockIdx.x * 2 + 1] = acc[1]; }
 }
 
+// partial[c] = {sum, sum^2} in fp64 from the conv epilogue's per-tile fp32 sums stat[part][pitch][2]
+__global__ __launch_bounds__(256) void bn_partials_kernel(const float* __restrict__ stat, int nparts, int pitch, double* __restrict__ partial) {
+    __shared__ double red[8];
+    const int c = blockIdx.x;
+    double acc[2] = {0.0, 0.0};
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(stat + ((int64_t)p * pitch + c) * 2);
+        acc[0] += (double)v.x;
+        acc[1] += (double)v.y;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { partial[(int64_t)c * 2] = acc[0]; partial[(int64_t)c * 2 + 1] = acc[1]; }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ partial, int C, int split, double count, float eps, float momentum,
                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var) {
@@ -900,6 +914,29 @@ int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, eps, running_mean, running_var, save_mean, save_invstd);
         DCV_LAUNCH_CHECK();
     }
+    BnApply f{x, y, rv(*xd), rv(*yd), gamma, beta, save_mean, save_invstd, mask, act, slope};
+    return launch_ew(m, f, s);
+}
+
+int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* mask,
+                             float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !stat || nparts < 1 || !same_shape(*xd, *yd) || pitch < xd->c)
+        return fail(DCV_EINVAL, "bn_act_forward_stats: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int C = xd->c;
+    const dcv_dims5* views[2] = {xd, yd};
+    const void* ptrs[2] = {x, y};
+    RowMap m = make_rowmap(*xd, views, 2, ptrs);
+    if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
+    if (ws_bytes < dcv_bn_workspace_bytes(C) || !ws) return fail(DCV_EWORKSPACE, "bn_act_forward_stats: workspace too small");
+    double* partial = static_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_partials_kernel, dim3(C), dim3(256), 0, s, stat, nparts, pitch, partial);
+    DCV_LAUNCH_CHECK();
+    const double count = (double)xd->n * xd->d * xd->h * xd->w;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, 1, count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    DCV_LAUNCH_CHECK();
     BnApply f{x, y, rv(*xd), rv(*yd), gamma, beta, save_mean, save_invstd, mask, act, slope};
     return launch_ew(m, f, s);
 }

@@ -18,6 +18,9 @@ import torch.nn as nn
 
 from . import ops
 
+import os
+
+_FUSE_BN_STATS = os.environ.get("DCV_NO_BN_FUSION") is None
 _CONVS = (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)
 _BNS = (nn.BatchNorm2d, nn.BatchNorm3d)
 
@@ -43,7 +46,7 @@ def geom_of(conv) -> "ops.ConvGeom":
     return ops.conv_geom(conv.weight, conv.stride, conv.padding, isinstance(conv, nn.ConvTranspose2d))
 
 
-def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None):
+def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, partials=None):
     training = bn.training
     mask = None
     if dropout is not None and dropout.training:
@@ -51,7 +54,7 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None):
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
-                      bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out)
+                      bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, partials=partials if training else None)
 
 
 def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
@@ -59,6 +62,7 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
     op is a conv(+act) or a BatchNorm group."""
     layers = list(seq)
     i, n = 0, len(layers)
+    pending = None   # BatchNorm partial sums left by the conv that produced x (conv -> BN pairs in training mode)
     while i < n:
         layer = layers[i]
         nxt = layers[i + 1] if i + 1 < n else None
@@ -68,7 +72,9 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
                 x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None)
                 i += 2
             else:
-                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None)
+                box = [] if (isinstance(nxt, _BNS) and nxt.training and _FUSE_BN_STATS) else None
+                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None, bn_stats=box)
+                pending = box[0] if box else None
                 i += 1
         elif isinstance(layer, _BNS):
             j = i + 1
@@ -79,7 +85,8 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
             fused = _act_of(layers[j]) if j < n else None
             if fused is not None:
                 j += 1
-            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop, out=out if j >= n else None)
+            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop, out=out if j >= n else None, partials=pending)
+            pending = None
             i = j
         elif _act_of(layer) is not None:
             code, slope = _act_of(layer)

@@ -49,10 +49,13 @@ _SIGS = {
     "dcv_debug_kernel_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dcv_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_conv_stats_bytes": (C.c_size_t, [_G, _D, _D]),
+    "dcv_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t, _P]),
     "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
     "dcv_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
     "dcv_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "dcv_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_bn_act_forward_stats": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "dcv_bn_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "dcv_act_forward": (C.c_int, [_P, _D, _P, _D, C.c_int, C.c_float, _P]),
     "dcv_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, C.c_int, C.c_float, _P]),

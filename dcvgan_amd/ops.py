@@ -79,6 +79,14 @@ class _Out:
         self.t = t
 
 
+class _Opaque:
+    """Non-tensor payload handed through Function.apply (autograd ignores it)."""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v
+
+
 def _dest(out, shape, device):
     if out is None:
         return _empty(shape, device)
@@ -91,7 +99,7 @@ def _dest(out, shape, device):
 
 class _Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
@@ -103,7 +111,17 @@ class _Conv(Function):
         if need == 0:
             raise N.NativeError("conv forward: " + L.dcv_last_error().decode())
         wsp, wsn = _ws("conv", need, x.device)
-        check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_conv_forward")
+        sbytes = L.dcv_conv_stats_bytes(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE) else 0
+        if sbytes:
+            # conv -> BatchNorm pair: the epilogue leaves per-tile {sum, sum^2} of y, the BN op skips its pass over y
+            stat = torch.empty(sbytes // 4, dtype=torch.float32, device=x.device)
+            nparts, pitch = C.c_int(0), C.c_int(0)
+            check(L.dcv_conv_forward_stats(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), ptr(stat), sbytes,
+                                           C.byref(nparts), C.byref(pitch), wsp, wsn, stream_ptr()), "dcv_conv_forward_stats")
+            if nparts.value > 0:
+                bn_stats.append((stat, nparts.value, pitch.value))
+        else:
+            check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_conv_forward")
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -132,13 +150,13 @@ class _Conv(Function):
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None):
     """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries.
     `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into."""
-    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out))
+    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats)
 
 
 # --------------------------------------------------------------------------- #
@@ -146,7 +164,8 @@ def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None):
 # --------------------------------------------------------------------------- #
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float, out=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float, out=None,
+                partials=None):
         N._require(x, "bn input")
         L = lib()
         Cn = x.shape[1]
@@ -154,9 +173,15 @@ class _BnAct(Function):
         stats = _empty((2, Cn), x.device)
         xd, yd = dims5(x), dims5(y)
         wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
-        check(L.dcv_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                   ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope, wsp, wsn, stream_ptr()),
-              "dcv_bn_act_forward")
+        if partials is not None and training:
+            stat, nparts, pitch = partials.v
+            check(L.dcv_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                             ptr(stats[0]), ptr(stats[1]), ptr(mask), momentum, eps, act, slope, ptr(stat), nparts, pitch,
+                                             wsp, wsn, stream_ptr()), "dcv_bn_act_forward_stats")
+        else:
+            check(L.dcv_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                       ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope, wsp, wsn, stream_ptr()),
+                  "dcv_bn_act_forward")
         ctx.cfg = (bool(training), act, slope)
         ctx.save_for_backward(x, gamma, beta, stats, mask)
         return y
@@ -175,14 +200,15 @@ class _BnAct(Function):
         check(L.dcv_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta),
                                     ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()),
               "dcv_bn_act_backward")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0,
-           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None):
-    """y = act(mask * batch_norm(x)); running stats are updated in place when training."""
+           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None, partials=None):
+    """y = act(mask * batch_norm(x)); running stats are updated in place when training.
+    `partials`: (buffer, nparts, pitch) left by the producing conv's epilogue (ops.conv(..., bn_stats=[]))."""
     return _BnAct.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope),
-                        None if out is None else _Out(out))
+                        None if out is None else _Out(out), None if partials is None else _Opaque(partials))
 
 
 # --------------------------------------------------------------------------- #

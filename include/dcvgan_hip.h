@@ -79,6 +79,12 @@ size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, cons
 int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w,
                      float* y, const dcv_dims5* yd, int act, float slope,
                      void* ws, size_t ws_bytes, void* stream);
+/* conv forward that also leaves per-tile BatchNorm partial sums of y (a conv -> BatchNorm pair, generator.py /
+ * discriminator.py blocks): stat[part][pitch][2] = {sum, sum of squares}; *nparts = 0 when this geometry's
+ * kernel cannot produce them (the caller then runs the plain statistics pass).  No activation, no accumulate. */
+size_t dcv_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
+int dcv_conv_forward_stats(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
+                           float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream);
 int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w,
                            float* dx, const dcv_dims5* dxd, int accumulate,
                            void* ws, size_t ws_bytes, void* stream);
@@ -105,6 +111,11 @@ int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_
                        int act, float slope, void* ws, size_t ws_bytes, void* stream);
 /* dx, dgamma, dbeta from dy; x is the BN input, y unused. dgamma/dbeta are
  * OVERWRITTEN (C floats each). */
+/* dcv_bn_act_forward with the batch statistics taken from dcv_conv_forward_stats' partial sums (training mode) */
+int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* mask,
+                             float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch,
+                             void* ws, size_t ws_bytes, void* stream);
 int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, const dcv_dims5* xd,
                         float* dx, const dcv_dims5* dxd,
                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
