@@ -762,9 +762,6 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     __builtin_amdgcn_sched_barrier(0);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated last-step DMAs must land before LDS is released
-#ifdef DCV_EXP_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
 #ifdef DCV_STAMP
     const unsigned long long q_epi = clock64();
 #define DCV_STAMP_OUT()                                                                                      \

@@ -263,3 +263,37 @@ def test_wgrad_long_reduction_accuracy(dev):
     (y * dy.to(dev)).sum().backward()
     e_hip = rel(wd.grad, w64.grad); e_cpu = rel(w32.grad, w64.grad)
     assert e_hip < 1e-5 and e_hip < 5 * max(e_cpu, 2e-7), (e_hip, e_cpu)
+
+
+def test_conv_bn_fused_statistics(dev):
+    """conv -> BatchNorm pair: the batch statistics taken from the GEMM epilogue's per-tile partial sums give the
+    same BN output, saved statistics, running statistics and gradients as the separate statistics pass."""
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(11)
+    nfused = 0
+    # small problems run split-K (no fused sums: the BN op must then fall back by itself); the 96-sample one does not
+    for tr, cin, cout, sp, n in ((False, 16, 40, (64, 64), 96), (True, 24, 130, (8, 8), 7), (False, 8, 36, (5, 16, 16), 2)):
+        nd = len(sp)
+        k = 4
+        s_t = (2, 2) if nd == 2 else (1, 2, 2)
+        p_t = (1, 1) if nd == 2 else (0, 1, 1)
+        wshape = ((cin, cout) if tr else (cout, cin)) + (k,) * nd
+        w0 = (torch.randn(wshape, generator=g) * 0.1).to(dev)
+        x0 = torch.randn((n, cin) + sp, generator=g).to(dev)
+        gamma0 = (torch.rand(cout, generator=g) + 0.5).to(dev); beta0 = torch.randn(cout, generator=g).to(dev)
+        res = []
+        for fused in (True, False):
+            x = x0.clone().requires_grad_(True); w = w0.clone().requires_grad_(True)
+            gamma = gamma0.clone().requires_grad_(True); beta = beta0.clone().requires_grad_(True)
+            rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+            geom = ops.conv_geom(w, s_t, p_t, tr)
+            box = [] if fused else None
+            y = ops.conv(x, w, geom, bn_stats=box)
+            nfused += bool(box)
+            z = ops.bn_act(y, gamma, beta, rm, rv, True, ops.ACT_LEAKY, 0.2, partials=box[0] if box else None)
+            cot = torch.cos(torch.arange(z.numel(), device=dev, dtype=torch.float32)).view(z.shape)
+            gr = torch.autograd.grad((z * cot).sum(), [x, w, gamma, beta])
+            res.append([z.detach(), rm, rv] + [t for t in gr])
+        for a, b in zip(*res):
+            assert rel(a.cpu(), b.cpu()) < 1e-5
+    assert nfused >= 1
