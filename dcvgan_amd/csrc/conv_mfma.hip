@@ -980,6 +980,97 @@ __global__ __launch_bounds__(256) void thin_struct_kernel(const GatherArgs a, in
         }
 }
 
+// --------------------------------------------------------------------------- //
+// thin_row64_kernel: OC <= 4, 3x3 taps, unit stride, rows exactly one wave wide (64 columns) — the colour
+// generator's RGB head (128 -> 3 at 64x64) and the data gradient of its 1 -> 64 stem.  thin_struct_kernel is
+// L1-bound there (9 dword gathers per channel and position).  Here a lane owns one column and FOUR consecutive
+// output rows: per channel the 6 input rows they share are loaded once (coalesced 256-byte rows), the left /
+// right neighbours come from DPP wave shifts (lanes 0 / 63 receive the zero padding through bound_ctrl), and
+// 36 x NOC FMAs run on them: 6 loads instead of 36 per channel and four outputs.  The 4 waves split the channels.
+// --------------------------------------------------------------------------- //
+template <int NOC>
+__global__ __launch_bounds__(256) void thin_row64_kernel(const GatherArgs a, int RC) {
+    __shared__ float red[3][4 * NOC][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ohq = (uint32_t)a.OH >> 2;
+    const uint32_t plane = blockIdx.x / ohq;
+    const int oh0 = (int)(blockIdx.x - plane * ohq) * 4;
+    const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base + a.td.delta[0]) * a.x_sd), 0, 0x80000000u, 0x00020000);
+    uint32_t vrow[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int ih = oh0 * a.th.mul + a.p_ihmin + q;
+        vrow[q] = (unsigned)ih < (unsigned)a.th.size ? (uint32_t)(4 * (ih * a.x_sh + lane)) : 0x80000000u;
+    }
+    int perm[9];   // packed-weight tap of (row offset, column offset)
+    {
+        typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+        const i32x16 sl16 = *reinterpret_cast<const i32x16*>(a.s_local);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) perm[t] = sl16[t];
+    }
+    float acc[4][NOC];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) acc[p][c] = 0.f;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (int rc = wave; rc < RC; rc += 4) {
+        const int soff = rc * a.s_stepA;
+        float r[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) r[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vrow[q], soff, 0));
+        const f32x4* __restrict__ wrow = reinterpret_cast<const f32x4*>(a.wp) + (int64_t)rc * 9;   // wave-uniform
+        f32x4 w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = wrow[perm[t]];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float v[3];
+            v[1] = r[q];
+            v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[q]), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> column - 1
+            v[2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[q]), 0x130, 0xf, 0xf, true));   // wave_shl:1 -> column + 1
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int ra = q - p;   // row offset of input row q for output row p
+                if (ra < 0 || ra > 2) continue;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const f32x4 wt = w[ra * 3 + b];
+                    acc[p][0] += wt[0] * v[b];
+                    if (NOC > 1) acc[p][1] += wt[1] * v[b];
+                    if (NOC > 2) acc[p][2] += wt[2] * v[b];
+                    if (NOC > 3) acc[p][3] += wt[3] * v[b];
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < NOC; ++c) red[wave - 1][p * NOC + c][lane] = acc[p][c];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int OC = a.OC, act = a.act, accumulate = a.accumulate;
+    const float slope = a.slope;
+    float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)lane * a.y_sw;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < NOC; ++c) {
+            if (c >= OC) continue;
+            float v = acc[p][c] + ((red[0][p * NOC + c][lane] + red[1][p * NOC + c][lane]) + red[2][p * NOC + c][lane]);
+            float* q = yb + (int64_t)(oh0 + p) * a.y_sh + (int64_t)c * a.y_sc;
+            if (accumulate) v += *q;
+            *q = apply_act(v, act, slope);
+        }
+}
+
 template <int T>
 static bool launch_thin_struct(const GatherArgs& a, int OC, int RC, int rc_per_split, dim3 grid, hipStream_t s) {
     switch (OC) {
@@ -1847,6 +1938,49 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                 if (rc2 != DCV_OK) return rc2;
                 npend = 0;
             }
+            continue;
+        }
+        // 3x3 / unit stride / 64-wide rows with OC <= 4: the row-reuse kernel
+        bool row64 = false;
+        if (tc.bn == 4 && KS2 == 1 && T == 9 && c.taps[0].n == 1 && c.taps[1].n == 3 && c.taps[2].n == 3 && c.o_ext[2] == 64 &&
+            c.taps[2].size == 64 && c.taps[1].mul == 1 && c.taps[2].mul == 1 && xd.sw == 1 && c.o_ext[1] % 4 == 0 &&
+            c.out_mul[1] == 1 && c.out_mul[2] == 1 && getenv("DCV_NO_ROW64") == nullptr && xd.sc * 4 < (1ll << 30)) {
+            auto range3 = [](const DimTaps& t, int* dmin) {
+                int lo = std::min(t.delta[0], std::min(t.delta[1], t.delta[2])), hi = std::max(t.delta[0], std::max(t.delta[1], t.delta[2]));
+                *dmin = lo;
+                return hi - lo == 2;
+            };
+            int dminh = 0, dminw = 0;
+            if (range3(c.taps[1], &dminh) && range3(c.taps[2], &dminw) && c.taps[2].base + dminw == -1) {
+                row64 = true;
+                a.p_ihmin = c.taps[1].base + dminh;
+                a.s_stepA = (int32_t)(xd.sc * 4);
+                for (int ra = 0; ra < 3; ++ra)
+                    for (int b = 0; b < 3; ++b) {
+                        int uh = 0, uw = 0;
+                        for (int u = 0; u < 3; ++u) {
+                            if (c.taps[1].delta[u] - dminh == ra) uh = u;
+                            if (c.taps[2].delta[u] - dminw == b) uw = u;
+                        }
+                        a.s_local[ra * 3 + b] = uh * 3 + uw;
+                    }
+            }
+        }
+        if (row64) {
+            if (npack > 0) {
+                int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
+                if (rcp != DCV_OK) return rcp;
+                npack = 0;
+                packmax = 0;
+            }
+            const dim3 g64((unsigned)(M64 / 256));
+            switch (OC) {
+                case 1: hipLaunchKernelGGL(thin_row64_kernel<1>, g64, dim3(256), 0, stream, a, RC); break;
+                case 2: hipLaunchKernelGGL(thin_row64_kernel<2>, g64, dim3(256), 0, stream, a, RC); break;
+                case 3: hipLaunchKernelGGL(thin_row64_kernel<3>, g64, dim3(256), 0, stream, a, RC); break;
+                default: hipLaunchKernelGGL(thin_row64_kernel<4>, g64, dim3(256), 0, stream, a, RC); break;
+            }
+            DCV_LAUNCH_CHECK();
             continue;
         }
         if (tc.bn == 4 && thin_struct) {
