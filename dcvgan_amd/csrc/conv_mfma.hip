@@ -981,36 +981,47 @@ __global__ __launch_bounds__(256) void thin_struct_kernel(const GatherArgs a, in
 }
 
 // --------------------------------------------------------------------------- //
-// thin_row64_kernel: OC <= 4, 3x3 taps, unit stride, rows exactly one wave wide (64 columns) — the colour
-// generator's RGB head (128 -> 3 at 64x64) and the data gradient of its 1 -> 64 stem.  thin_struct_kernel is
-// L1-bound there (9 dword gathers per channel and position).  Here a lane owns one column and FOUR consecutive
-// output rows: per channel the 6 input rows they share are loaded once (coalesced 256-byte rows), the left /
-// right neighbours come from DPP wave shifts (lanes 0 / 63 receive the zero padding through bound_ctrl), and
-// 36 x NOC FMAs run on them: 6 loads instead of 36 per channel and four outputs.  The 4 waves split the channels.
+// thin_rows_kernel: OC <= 4, unit stride, rows one wave (64) or half a wave (32) wide, 2-3 taps per spatial
+// dim, 1 or 4 depth taps — the colour generator's RGB head (128 -> 3, 3x3 at 64x64), the data gradient of its
+// 1 -> 64 stem, the depth head of the geometry generator and the data gradients of the 3-D discriminators'
+// stems (stride-parity classes of 4x4(x4) filters: 2x2(x4) taps on 32-wide class grids).  thin_struct_kernel
+// is L1-bound there (one dword gather per tap, channel and position).  Here a lane owns one column and FOUR
+// consecutive output rows: per channel (and depth tap) the NH + 3 input rows they share are loaded once
+// (coalesced rows), the left / right neighbours come from DPP wave shifts (the wave's end lanes receive the
+// zero padding through bound_ctrl; 32-wide rows mask the lanes at the seam), and 4 x NH x NW x NOC FMAs run
+// on them.  Depth taps that fall outside the clip are skipped per workgroup.  The 4 waves split the channels.
 // --------------------------------------------------------------------------- //
-template <int NOC>
-__global__ __launch_bounds__(256) void thin_row64_kernel(const GatherArgs a, int RC) {
+template <int NOC, int NH, int NW, int ND, bool W32, int IW0>
+__global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int RC) {
+    constexpr int NR = NH + 3, T = ND * NH * NW, RPB = W32 ? 8 : 4;   // input rows per lane, taps per channel, output rows per block
     __shared__ float red[3][4 * NOC][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t ohq = (uint32_t)a.OH >> 2;
+    const int col = W32 ? (lane & 31) : lane;
+    const uint32_t ohq = (uint32_t)a.OH / RPB;
     const uint32_t plane = blockIdx.x / ohq;
-    const int oh0 = (int)(blockIdx.x - plane * ohq) * 4;
+    const int oh0 = (int)(blockIdx.x - plane * ohq) * RPB + (W32 ? 4 * (lane >> 5) : 0);   // this lane's first output row
     const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x + (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base + a.td.delta[0]) * a.x_sd), 0, 0x80000000u, 0x00020000);
-    uint32_t vrow[6];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)n * a.x_sn), 0, 0x80000000u, 0x00020000);
+    uint32_t vrow[NR];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int ih = oh0 * a.th.mul + a.p_ihmin + q;
-        vrow[q] = (unsigned)ih < (unsigned)a.th.size ? (uint32_t)(4 * (ih * a.x_sh + lane)) : 0x80000000u;
+    for (int q = 0; q < NR; ++q) {
+        const int ih = oh0 + a.p_ihmin + q;
+        vrow[q] = (unsigned)ih < (unsigned)a.th.size ? (uint32_t)(4 * (ih * a.x_sh + col)) : 0x80000000u;
     }
-    int perm[9];   // packed-weight tap of (row offset, column offset)
+    // depth taps: byte offset of the gathered depth slice, or -1 when it is outside the clip (block-uniform)
+    int doff[ND];
+#pragma unroll
+    for (int ud = 0; ud < ND; ++ud) {
+        const int id = (int)od * a.td.mul + a.td.base + a.td.delta[ud];
+        doff[ud] = (unsigned)id < (unsigned)a.td.size ? 4 * id * a.x_sd : -1;
+    }
+    int perm[T];   // packed-weight tap of (depth tap, row offset, column offset)
     {
         typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
         const i32x16 sl16 = *reinterpret_cast<const i32x16*>(a.s_local);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) perm[t] = sl16[t];
+        for (int t = 0; t < T; ++t) perm[t] = sl16[t];
     }
     float acc[4][NOC];
 #pragma unroll
@@ -1019,31 +1030,41 @@ __global__ __launch_bounds__(256) void thin_row64_kernel(const GatherArgs a, int
         for (int c = 0; c < NOC; ++c) acc[p][c] = 0.f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     for (int rc = wave; rc < RC; rc += 4) {
-        const int soff = rc * a.s_stepA;
-        float r[6];
+        const f32x4* __restrict__ wrow = reinterpret_cast<const f32x4*>(a.wp) + (int64_t)rc * T;   // wave-uniform
 #pragma unroll
-        for (int q = 0; q < 6; ++q) r[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vrow[q], soff, 0));
-        const f32x4* __restrict__ wrow = reinterpret_cast<const f32x4*>(a.wp) + (int64_t)rc * 9;   // wave-uniform
-        f32x4 w[9];
+        for (int ud = 0; ud < ND; ++ud) {
+            if (doff[ud] < 0) continue;
+            const int soff = rc * a.s_stepA + doff[ud];
+            float r[NR];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = wrow[perm[t]];
+            for (int q = 0; q < NR; ++q) r[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vrow[q], soff, 0));
+            f32x4 w[NH * NW];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            float v[3];
-            v[1] = r[q];
-            v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[q]), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> column - 1
-            v[2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[q]), 0x130, 0xf, 0xf, true));   // wave_shl:1 -> column + 1
+            for (int t = 0; t < NH * NW; ++t) w[t] = wrow[perm[ud * NH * NW + t]];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int ra = q - p;   // row offset of input row q for output row p
-                if (ra < 0 || ra > 2) continue;
+            for (int q = 0; q < NR; ++q) {
+                // columns col + IW0 + b, b = 0 .. NW-1, as offsets -1 / 0 / +1 from this lane's column
+                float v[3];
+                v[1] = r[q];
+                v[0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[q]), 0x138, 0xf, 0xf, true));   // wave_shr:1
+                v[2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r[q]), 0x130, 0xf, 0xf, true));   // wave_shl:1
+                if (W32) {   // the seam between the two 32-wide rows of the wave is padding, not a neighbour
+                    v[0] = col == 0 ? 0.f : v[0];
+                    v[2] = col == 31 ? 0.f : v[2];
+                }
 #pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const f32x4 wt = w[ra * 3 + b];
-                    acc[p][0] += wt[0] * v[b];
-                    if (NOC > 1) acc[p][1] += wt[1] * v[b];
-                    if (NOC > 2) acc[p][2] += wt[2] * v[b];
-                    if (NOC > 3) acc[p][3] += wt[3] * v[b];
+                for (int p = 0; p < 4; ++p) {
+                    const int ra = q - p;   // row offset of input row q for output row p
+                    if (ra < 0 || ra >= NH) continue;
+#pragma unroll
+                    for (int b = 0; b < NW; ++b) {
+                        const f32x4 wt = w[ra * NW + b];
+                        const float xv = v[IW0 + b + 1];
+                        acc[p][0] += wt[0] * xv;
+                        if (NOC > 1) acc[p][1] += wt[1] * xv;
+                        if (NOC > 2) acc[p][2] += wt[2] * xv;
+                        if (NOC > 3) acc[p][3] += wt[3] * xv;
+                    }
                 }
             }
         }
@@ -1058,7 +1079,7 @@ __global__ __launch_bounds__(256) void thin_row64_kernel(const GatherArgs a, int
     if (wave != 0) return;
     const int OC = a.OC, act = a.act, accumulate = a.accumulate;
     const float slope = a.slope;
-    float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)lane * a.y_sw;
+    float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)col * a.y_sw;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -1069,6 +1090,16 @@ __global__ __launch_bounds__(256) void thin_row64_kernel(const GatherArgs a, int
             if (accumulate) v += *q;
             *q = apply_act(v, act, slope);
         }
+}
+
+template <int NH, int NW, int ND, bool W32, int IW0>
+static void launch_thin_rows(const GatherArgs& a, int OC, int RC, dim3 grid, hipStream_t s) {
+    switch (OC) {
+        case 1: hipLaunchKernelGGL((thin_rows_kernel<1, NH, NW, ND, W32, IW0>), grid, dim3(256), 0, s, a, RC); break;
+        case 2: hipLaunchKernelGGL((thin_rows_kernel<2, NH, NW, ND, W32, IW0>), grid, dim3(256), 0, s, a, RC); break;
+        case 3: hipLaunchKernelGGL((thin_rows_kernel<3, NH, NW, ND, W32, IW0>), grid, dim3(256), 0, s, a, RC); break;
+        default: hipLaunchKernelGGL((thin_rows_kernel<4, NH, NW, ND, W32, IW0>), grid, dim3(256), 0, s, a, RC); break;
+    }
 }
 
 template <int T>
@@ -1940,46 +1971,53 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
             continue;
         }
-        // 3x3 / unit stride / 64-wide rows with OC <= 4: the row-reuse kernel
-        bool row64 = false;
-        if (tc.bn == 4 && KS2 == 1 && T == 9 && c.taps[0].n == 1 && c.taps[1].n == 3 && c.taps[2].n == 3 && c.o_ext[2] == 64 &&
-            c.taps[2].size == 64 && c.taps[1].mul == 1 && c.taps[2].mul == 1 && xd.sw == 1 && c.o_ext[1] % 4 == 0 &&
-            c.out_mul[1] == 1 && c.out_mul[2] == 1 && getenv("DCV_NO_ROW64") == nullptr && xd.sc * 4 < (1ll << 30)) {
-            auto range3 = [](const DimTaps& t, int* dmin) {
-                int lo = std::min(t.delta[0], std::min(t.delta[1], t.delta[2])), hi = std::max(t.delta[0], std::max(t.delta[1], t.delta[2]));
-                *dmin = lo;
-                return hi - lo == 2;
-            };
-            int dminh = 0, dminw = 0;
-            if (range3(c.taps[1], &dminh) && range3(c.taps[2], &dminw) && c.taps[2].base + dminw == -1) {
-                row64 = true;
-                a.p_ihmin = c.taps[1].base + dminh;
-                a.s_stepA = (int32_t)(xd.sc * 4);
-                for (int ra = 0; ra < 3; ++ra)
-                    for (int b = 0; b < 3; ++b) {
-                        int uh = 0, uw = 0;
-                        for (int u = 0; u < 3; ++u) {
-                            if (c.taps[1].delta[u] - dminh == ra) uh = u;
-                            if (c.taps[2].delta[u] - dminw == b) uw = u;
-                        }
-                        a.s_local[ra * 3 + b] = uh * 3 + uw;
-                    }
+        // OC <= 4, unit stride, 32- or 64-wide rows, (3x3 | 2x2 | 2x2x4) taps: the row-reuse kernel
+        int rows_kind = 0;   // 1: 3x3 @64   2: 2x2 @32   3: 2x2x4 @32
+        int rows_iw0 = 0;
+        if (tc.bn == 4 && KS2 == 1 && xd.sw == 1 && c.taps[0].mul == 1 && c.taps[1].mul == 1 && c.taps[2].mul == 1 &&
+            c.o_ext[2] == c.taps[2].size && getenv("DCV_NO_ROW64") == nullptr && xd.sc * 4 < (1ll << 30) && xd.sd * 4 * 8 < (1ll << 30)) {
+            const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n, OWc = c.o_ext[2], OHc = c.o_ext[1];
+            if (nd == 1 && nh == 3 && nw == 3 && OWc == 64 && OHc % 4 == 0) rows_kind = 1;
+            else if (nd == 1 && nh == 2 && nw == 2 && OWc == 32 && OHc % 8 == 0) rows_kind = 2;
+            else if (nd == 4 && nh == 2 && nw == 2 && OWc == 32 && OHc % 8 == 0) rows_kind = 3;
+            if (rows_kind) {
+                auto span = [](const DimTaps& t, int* dmin) {
+                    int lo = t.delta[0], hi = t.delta[0];
+                    for (int u = 1; u < t.n; ++u) { lo = std::min(lo, t.delta[u]); hi = std::max(hi, t.delta[u]); }
+                    *dmin = lo;
+                    return hi - lo + 1 == t.n;
+                };
+                int dminh = 0, dminw = 0;
+                const bool ok = span(c.taps[1], &dminh) && span(c.taps[2], &dminw);
+                rows_iw0 = c.taps[2].base + dminw;
+                if (!ok || rows_iw0 < -1 || rows_iw0 + nw - 1 > 1 || (rows_kind == 1 && rows_iw0 != -1)) rows_kind = 0;
+                else {
+                    a.p_ihmin = c.taps[1].base + dminh;
+                    a.s_stepA = (int32_t)(xd.sc * 4);
+                    for (int ud = 0; ud < nd; ++ud)
+                        for (int ra = 0; ra < nh; ++ra)
+                            for (int b = 0; b < nw; ++b) {
+                                int uh = 0, uw = 0;
+                                for (int u = 0; u < nh; ++u) if (c.taps[1].delta[u] - dminh == ra) uh = u;
+                                for (int u = 0; u < nw; ++u) if (c.taps[2].delta[u] - dminw == b) uw = u;
+                                a.s_local[(ud * nh + ra) * nw + b] = (ud * nh + uh) * nw + uw;
+                            }
+                }
             }
         }
-        if (row64) {
+        if (rows_kind) {
             if (npack > 0) {
                 int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
                 if (rcp != DCV_OK) return rcp;
                 npack = 0;
                 packmax = 0;
             }
-            const dim3 g64((unsigned)(M64 / 256));
-            switch (OC) {
-                case 1: hipLaunchKernelGGL(thin_row64_kernel<1>, g64, dim3(256), 0, stream, a, RC); break;
-                case 2: hipLaunchKernelGGL(thin_row64_kernel<2>, g64, dim3(256), 0, stream, a, RC); break;
-                case 3: hipLaunchKernelGGL(thin_row64_kernel<3>, g64, dim3(256), 0, stream, a, RC); break;
-                default: hipLaunchKernelGGL(thin_row64_kernel<4>, g64, dim3(256), 0, stream, a, RC); break;
-            }
+            const dim3 gr((unsigned)(M64 / 256));
+            if (rows_kind == 1) launch_thin_rows<3, 3, 1, false, -1>(a, OC, RC, gr, stream);
+            else if (rows_kind == 2 && rows_iw0 == -1) launch_thin_rows<2, 2, 1, true, -1>(a, OC, RC, gr, stream);
+            else if (rows_kind == 2) launch_thin_rows<2, 2, 1, true, 0>(a, OC, RC, gr, stream);
+            else if (rows_iw0 == -1) launch_thin_rows<2, 2, 4, true, -1>(a, OC, RC, gr, stream);
+            else launch_thin_rows<2, 2, 4, true, 0>(a, OC, RC, gr, stream);
             DCV_LAUNCH_CHECK();
             continue;
         }
