@@ -798,23 +798,46 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 
 // y = act( sum_s slab[s][oc][m] (+ y) ), scattered to the NCDHW output; fixed summation order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GatherArgsPack pack, int S) {
+    // 4 consecutive positions per thread (16-byte slab loads), 4 slabs in flight; 32-bit index math
     const GatherArgs& a = pack.c[blockIdx.y];
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int m = (int)(idx % a.Mp), oc = (int)(idx / a.Mp);
-    if (m >= a.M || oc >= a.OC) return;
-    const float* __restrict__ p = a.slab + (int64_t)oc * a.Mp + m;
-    const int64_t stride = (int64_t)a.OCp * a.Mp;
-    float v = 0.f;
-    for (int k = 0; k < S; ++k) v += p[k * stride];
-    const uint32_t n = fdiv((uint32_t)m, a.div_sp);
-    uint32_t r0 = (uint32_t)m - n * a.div_sp.div;
-    const uint32_t od = fdiv(r0, a.div_hw);
-    r0 -= od * a.div_hw.div;
-    const uint32_t oh = fdiv(r0, a.div_w);
-    const uint32_t ow = r0 - oh * a.div_w.div;
-    float* q = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)oc * a.y_sc + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
-    if (a.accumulate) v += *q;
-    *q = apply_act(v, a.act, a.slope);
+    const uint32_t Mp = (uint32_t)a.Mp, M = (uint32_t)a.M, q4 = Mp >> 2;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t oc = idx / q4, m = (idx - oc * q4) * 4;
+    if (oc >= (uint32_t)a.OC || m >= M) return;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(a.slab + (int64_t)oc * Mp + m);
+    const int64_t stride = ((int64_t)a.OCp * Mp) >> 2;
+    float4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    int k = 0;
+    for (; k + 3 < S; k += 4) {
+        const float4 t0 = p[(int64_t)k * stride], t1 = p[(int64_t)(k + 1) * stride], t2 = p[(int64_t)(k + 2) * stride], t3 = p[(int64_t)(k + 3) * stride];
+        v0.x += t0.x; v0.y += t0.y; v0.z += t0.z; v0.w += t0.w;
+        v1.x += t1.x; v1.y += t1.y; v1.z += t1.z; v1.w += t1.w;
+        v2.x += t2.x; v2.y += t2.y; v2.z += t2.z; v2.w += t2.w;
+        v3.x += t3.x; v3.y += t3.y; v3.z += t3.z; v3.w += t3.w;
+    }
+    for (; k < S; ++k) {
+        const float4 t0 = p[(int64_t)k * stride];
+        v0.x += t0.x; v0.y += t0.y; v0.z += t0.z; v0.w += t0.w;
+    }
+    const float v[4] = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w)};
+    const int act = a.act, accumulate = a.accumulate;
+    const float slope = a.slope;
+    float* __restrict__ yb = a.y + a.y_off + (int64_t)oc * a.y_sc;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t me = m + e;
+        if (me >= M) break;
+        const uint32_t n = fdiv(me, a.div_sp);
+        uint32_t r0 = me - n * a.div_sp.div;
+        const uint32_t od = fdiv(r0, a.div_hw);
+        r0 -= od * a.div_hw.div;
+        const uint32_t oh = fdiv(r0, a.div_w);
+        const uint32_t ow = r0 - oh * a.div_w.div;
+        float* q = yb + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+        float x = v[e];
+        if (accumulate) x += *q;
+        *q = apply_act(x, act, slope);
+    }
 }
 
 // --------------------------------------------------------------------------- //
@@ -1649,7 +1672,7 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
-        for (int i = 0; i < n; ++i) tot = std::max<int64_t>(tot, (int64_t)OC * pend.c[i].Mp);
+        for (int i = 0; i < n; ++i) tot = std::max<int64_t>(tot, (int64_t)OC * (pend.c[i].Mp / 4));
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256), (unsigned)n), dim3(256), 0, stream, pend, KS);
         DCV_LAUNCH_CHECK();
     }
@@ -2032,7 +2055,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         else launch_gather<1, 2, 1, 4>(a, grid, stream);
         DCV_LAUNCH_CHECK();
         if (KS2 > 1) {
-            const int64_t tot = (int64_t)OC * Mp;
+            const int64_t tot = (int64_t)OC * (Mp / 4);
             GatherArgsPack one;
             for (int i = 0; i < 4; ++i) one.c[i] = a;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256), 1), dim3(256), 0, stream, one, KS2);
