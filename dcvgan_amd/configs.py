@@ -96,7 +96,7 @@ FLOPS_PER_VIDEO_STEP = {
     "isogd-depth": (166.12e9, 128.33e9),
     "surreal-depth1": (188.31e9, 142.41e9),
     "isogd-flow": (165.41e9, 127.29e9),
-    # torch.utils.flop_counter on the CPU oracle's step (reproduces 166.12e9 for isogd-depth); minimal = as-written
+    # torch.utils.flop_counter on a CPU restatement of the step (reproduces 166.12e9 for isogd-depth); minimal = as-written
     # minus the dead generator backward (2 x 25.83e9 generator forward)
     "surreal-segm": (204.08e9, 152.4e9),
 }
