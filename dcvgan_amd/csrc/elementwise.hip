@@ -4,6 +4,7 @@
 // of H*W contiguous floats (vectorised 16 B per lane); views whose (h, w) plane is
 // not contiguous fall back to rows of one element.
 #include "dcv_common.h"
+#include <algorithm>
 
 namespace dcv {
 
@@ -508,6 +509,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// up to ADAM_MT tensors of one optimiser in one launch (the DCVGAN models have ~100 small parameter tensors:
+// one launch each was ~100 x 5 us of dispatch per step for 70 MB of state)
+#define ADAM_MT 24
+struct AdamPack {
+    float* p[ADAM_MT];
+    const float* g[ADAM_MT];
+    float* m[ADAM_MT];
+    float* v[ADAM_MT];
+    int64_t n[ADAM_MT];
+    int32_t first_block[ADAM_MT + 1];   // prefix sum of the tensors' block counts (4096 elements per block)
+};
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamPack k, int nt, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    int t = 0;
+    while (t + 1 < nt && (int)blockIdx.x >= k.first_block[t + 1]) ++t;
+    const int64_t base = (int64_t)((int)blockIdx.x - k.first_block[t]) * 4096;
+    float* __restrict__ p = k.p[t];
+    const float* __restrict__ g = k.g[t];
+    float* __restrict__ m = k.m[t];
+    float* __restrict__ v = k.v[t];
+    const int64_t n = k.n[t];
+#pragma unroll 4
+    for (int e = 0; e < 16; ++e) {
+        const int64_t i = base + e * 256 + threadIdx.x;
+        if (i >= n) break;
+        const float pi = p[i];
+        const float gi = g[i] * gscale + wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
 // ------------------------------------------------------------------------- //
 // GRU recurrence (dm <= 32): one 64-lane block per sample, lane u < dm owns unit u
 // ------------------------------------------------------------------------- //
@@ -986,6 +1021,30 @@ int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     return DCV_OK;
 }
 
+
+int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!p || !g || !m || !v || !numel)) || step < 1) return fail(DCV_EINVAL, "adam_step_multi: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MT) {
+        AdamPack k;
+        memset(&k, 0, sizeof(k));
+        const int nt = std::min(ADAM_MT, n_tensors - t0);
+        int blocks = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (!p[t0 + t] || !g[t0 + t] || !m[t0 + t] || !v[t0 + t] || numel[t0 + t] < 0) return fail(DCV_EINVAL, "adam_step_multi: null tensor");
+            k.p[t] = p[t0 + t]; k.g[t] = g[t0 + t]; k.m[t] = m[t0 + t]; k.v[t] = v[t0 + t]; k.n[t] = numel[t0 + t];
+            k.first_block[t] = blocks;
+            blocks += (int)((numel[t0 + t] + 4095) / 4096);
+        }
+        k.first_block[nt] = blocks;
+        if (blocks == 0) continue;
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), k, nt, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+        DCV_LAUNCH_CHECK();
+    }
+    return DCV_OK;
+}
 
 int dcv_decode_video(const void* in, int in_is_u8, int B, int T, int H, int W, int Cc, float div, float sub, float* out, void* stream) {
     if (!in || !out || B < 1 || T < 1 || H < 1 || W < 1 || Cc < 1 || div == 0.f) return fail(DCV_EINVAL, "decode_video: bad arguments");

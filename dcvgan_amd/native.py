@@ -76,6 +76,7 @@ _SIGS = {
     "dcv_gru_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dcv_gru_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dcv_gru_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_adam_step_multi": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
     "dcv_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
 }
 EXPORTS = tuple(_SIGS)

@@ -42,6 +42,8 @@ class Adam:
     def step(self):
         L = lib()
         st = stream_ptr()
+        ps, gs, ms, vs, ns, keep = [], [], [], [], [], []
+        step = None
         for p in self.params:
             g = p.grad
             if g is None:
@@ -54,8 +56,19 @@ class Adam:
             if s is None:
                 s = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)}
             s["step"] += 1
-            check(L.dcv_adam_step(ptr(p.data), ptr(g), ptr(s["exp_avg"]), ptr(s["exp_avg_sq"]), p.numel(), self.lr, self.betas[0], self.betas[1],
-                                  self.eps, self.weight_decay, s["step"], self.grad_scale, st), "dcv_adam_step")
+            if step is None:
+                step = s["step"]
+            if s["step"] != step:   # parameters that joined later keep their own bias correction: single-tensor path
+                check(L.dcv_adam_step(ptr(p.data), ptr(g), ptr(s["exp_avg"]), ptr(s["exp_avg_sq"]), p.numel(), self.lr, self.betas[0], self.betas[1],
+                                      self.eps, self.weight_decay, s["step"], self.grad_scale, st), "dcv_adam_step")
+                continue
+            ps.append(p.data.data_ptr()); gs.append(g.data_ptr()); ms.append(s["exp_avg"].data_ptr()); vs.append(s["exp_avg_sq"].data_ptr())
+            ns.append(p.numel()); keep.append(g)
+        n = len(ps)
+        if n:
+            arr = lambda xs: (C.c_void_p * n)(*xs)
+            check(L.dcv_adam_step_multi(n, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * n)(*ns), self.lr, self.betas[0], self.betas[1],
+                                        self.eps, self.weight_decay, step, self.grad_scale, st), "dcv_adam_step_multi")
 
 
 class DataParallelAdam:

@@ -197,6 +197,9 @@ int dcv_gru_backward(const float* dout, const float* e, const float* h0, const f
 int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, void* stream);
+/* the same update for n_tensors parameter tensors of one optimiser (one shared step count) in ceil(n/24) launches */
+int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }
