@@ -1790,7 +1790,9 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // ---- split-K decision: under-filled grids with a long K loop ----
         const int Mp = (int)((M64 + tc.bm - 1) / tc.bm * tc.bm);
         const int blocks = (OCp / tc.bn) * (Mp / tc.bm);
-        const int KS = gather_splits(blocks, KIT, tc.bn == 4);
+        // the classes of an op share one launch, so the grid to fill is all of them together (depth-step classes
+        // skip a varying share of their steps and measured better with the per-class count)
+        const int KS = gather_splits(tc.bn != 4 && !dstep ? blocks * (int)classes.size() : blocks, KIT, tc.bn == 4);
         const int kper = (KIT + KS - 1) / KS;
         const int KS2 = (KIT + kper - 1) / kper;
         // ---- pack weights ----
@@ -2087,7 +2089,7 @@ static size_t gather_ws_bytes(int RC, int OC, int N, const std::vector<GatherCla
         const int64_t M64 = (int64_t)N * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
         const int64_t Mp = (M64 + tc.bm - 1) / tc.bm * tc.bm;
         const int blocks = (int)((OCp / tc.bn) * (Mp / tc.bm));
-        const int KS = gather_splits(blocks, KIT, tc.bn == 4);
+        const int KS = gather_splits(blocks, KIT, tc.bn == 4);   // per-class count: an upper bound of run_gather's choice
         if (KS > 1) tot += align_up((size_t)KS * OCp * Mp * sizeof(float), 256);
     }
     return tot + 256;
