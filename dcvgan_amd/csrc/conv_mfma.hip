@@ -1394,8 +1394,10 @@ __device__ __forceinline__ void wgrad_tile_addr(const WgradArgs& a, int m, int m
     for (int t = 0; t < 16; ++t) gvo[t] = row[t >> 2] + col[t & 3];
 }
 
+// TD = dense-operand row tiles per wave: 2 -> 128 x 128 tile, 1 -> 64 x 128 (64-channel layers: cgen.down0, gdis.5)
+template <int TD>
 __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
-    constexpr int BD = 128, BJ = 128, P = 65, TILE = (BD + BJ) * P;
+    constexpr int BD = 64 * TD, BJ = 128, P = 65, TILE = (BD + BJ) * P, DR = 16 * TD;   // DR: dense rows DMA'd per wave
     __shared__ float smem[2 * TILE];
 
     const int tid = threadIdx.x;
@@ -1417,14 +1419,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     const int cd0 = (j0 >> 4) + wave * 2;   // (channel, depth tap) index of rows 0..15; rows 16..31 -> cd0 + 1
     const int gso0 = (cd0 >> a.log2nd) * a.g_sc4 + (cd0 & ((1 << a.log2nd) - 1)) * a.g_sd4;
     const int gso1 = ((cd0 + 1) >> a.log2nd) * a.g_sc4 + ((cd0 + 1) & ((1 << a.log2nd) - 1)) * a.g_sd4;
-    const int dso0 = (d0 + wave * 32) * a.d_sc4;
+    const int dso0 = (d0 + wave * DR) * a.d_sc4;
 
     // two-level accumulation (registers are free at one wave per SIMD): the MFMA adds into `acc` as a
     // k-ordered fp32 chain; every 16 tiles (1024 positions) the chain is folded into `sum`, so no
     // partial sum is longer than 1024 terms before it meets a value of its own magnitude
-    f32x16 acc[2][2], sum[2][2];
+    f32x16 acc[TD][2], sum[TD][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TD; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1437,7 +1439,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // row I (0..31) of this wave's dense / gathered share of the tile in buffer BUF
 #define DCV_WG_DROW(BUF, I) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(smem + (BUF) * TILE + (wave * 32 + (I)) * P), 4, dvo, dso0 + (I) * a.d_sc4, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(smem + (BUF) * TILE + (wave * DR + (I)) * P), 4, dvo, dso0 + (I) * a.d_sc4, 0, 0);
 #define DCV_WG_GROW(BUF, I) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void*)(smem + (BUF) * TILE + (BD + wave * 32 + (I)) * P), 4, gvo[(I) & 15], ((I) < 16 ? gso0 : gso1), 0, 0);
 #else
@@ -1449,7 +1451,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     if (nit > 0) {
         DCV_WG_ADDR(0, dvo, gvo)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { DCV_WG_DROW(0, i) DCV_WG_GROW(0, i) }
+        for (int i = 0; i < 32; ++i) { if (i < DR) { DCV_WG_DROW(0, i < DR ? i : 0) } DCV_WG_GROW(0, i) }
         DCV_WG_ADDR(min(1, nit - 1), dvo, gvo)   // voffsets of the tile whose DMAs the first loop step issues
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1462,44 +1464,53 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         const int buf = it & 1;
         STAMP(w0);
         // dvo / gvo hold tile min(it + 1, nit - 1) (last tile: a harmless repeat into the idle buffer)
-        const float* da = smem + buf * TILE + ((wd * 2) * 32 + l31) * P + lhi;
+        const float* da = smem + buf * TILE + ((wd * TD) * 32 + l31) * P + lhi;
         const float* gb = smem + buf * TILE + (BD + (wj * 2) * 32 + l31) * P + lhi;
         __builtin_amdgcn_s_setprio(2);
         // voffsets of the tile after next: plain VALU work with no consumer inside this step, free to be
         // scheduled into the shadow of the MFMAs below (one wave per SIMD: nothing else would hide it)
         DCV_WG_ADDR(min(it + 2, nit - 1), dvon, gvon)
-        float af[2][2], bf[2][2];
+        float af[2][TD], bf[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { af[0][i] = da[i * 32 * P]; bf[0][i] = gb[i * 32 * P]; }
+        for (int i = 0; i < 2; ++i) { if (i < TD) af[0][i < TD ? i : 0] = da[i * 32 * P]; bf[0][i] = gb[i * 32 * P]; }
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < 32) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { af[nxt][i] = da[i * 32 * P + 2 * (ks + 1)]; bf[nxt][i] = gb[i * 32 * P + 2 * (ks + 1)]; }
+                for (int i = 0; i < 2; ++i) { if (i < TD) af[nxt][i < TD ? i : 0] = da[i * 32 * P + 2 * (ks + 1)]; bf[nxt][i] = gb[i * 32 * P + 2 * (ks + 1)]; }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TD; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
-            // next tile's 64 row DMAs, three per k-step: the last one is issued at k-step 21 and has
-            // ten k-steps (2500 cycles) to land before the wait at the end of the tile
+            // next tile's DR + 32 row DMAs, three per k-step (dense rows first interleaved with gathered ones): the last
+            // one is issued about ten k-steps (2500 cycles) before the wait at the end of the tile
 #pragma unroll
             for (int q = 3 * ks; q < 3 * ks + 3; ++q)
-                if (q < 64) {
-                    if (q & 1) { DCV_WG_GROW(buf ^ 1, q >> 1) } else { DCV_WG_DROW(buf ^ 1, q >> 1) }
+                if (q < DR + 32) {
+                    if (q < 2 * DR) {
+                        if (q & 1) { DCV_WG_GROW(buf ^ 1, q >> 1) } else { DCV_WG_DROW(buf ^ 1, (q >> 1) < DR ? (q >> 1) : 0) }
+                    } else {
+                        DCV_WG_GROW(buf ^ 1, (q - DR) < 32 ? (q - DR) : 0)
+                    }
                 }
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (ks < 21) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
-            else if (ks == 21) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 + TD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TD, 0);
+            {
+                constexpr int NI = DR + 32;
+                const int left = NI - 3 * ks;
+                if (left >= 3) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
+                else if (left == 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                else if (left == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         STAMP(w1);
         if ((it & 15) == 15) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TD; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1524,12 +1535,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 
     float* __restrict__ out = a.slab + (int64_t)blockIdx.y * a.DCp * a.Jp;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TD; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int dc = d0 + (wd * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int dc = d0 + (wd * TD + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 const int jj = j0 + (wj * 2 + j) * 32 + l31;
                 out[(int64_t)dc * a.Jp + jj] = sum[i][j][r] + acc[i][j][r];
             }
@@ -2171,7 +2182,7 @@ struct WgradTile {
 static WgradTile pick_wgrad_tile(int DC, int J) {
     if (J <= 32) return WgradTile{128, 32};   // stems: few gathered channels x taps
     if (DC > 64) return (J > 64) ? WgradTile{128, 128} : WgradTile{128, 64};
-    if (DC > 32) return (J > 128) ? WgradTile{64, 256} : WgradTile{64, 128};
+    if (DC > 32) return (J > 128 && (DC != 64 || J % 128 != 0)) ? WgradTile{64, 256} : WgradTile{64, 128};   // 64 x 128: the LDS-DMA form
     return (J > 128) ? WgradTile{32, 256} : WgradTile{32, 128};
 }
 
@@ -2209,9 +2220,9 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
     const int tiles = (DCp / tc.bd) * (Jp / tc.bj);
     // double-buffered LDS-DMA form: 128 x 128 tile, 4x4 inner taps, un-padded depth taps, full channel tiles
-    bool dma = getenv("DCV_NO_WGRAD_DMA") == nullptr && tc.bd == 128 && tc.bj == 128 && k[1] == 4 && k[2] == 4 &&
+    bool dma = getenv("DCV_NO_WGRAD_DMA") == nullptr && ((tc.bd == 128 && tc.bj == 128) || (tc.bd == 64 && tc.bj == 128 && getenv("DCV_NO_WGRAD_DMA64") == nullptr)) && k[1] == 4 && k[2] == 4 &&
                (k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8) && (k[0] == 1 || (p[0] == 0 && s[0] == 1)) &&
-               DC % 128 == 0 && J % 128 == 0 && gd.sc * 4 < (1ll << 30) && dd.sc * 4 < (1ll << 30);
+               DC % tc.bd == 0 && J % 128 == 0 && gd.sc * 4 < (1ll << 30) && dd.sc * 4 < (1ll << 30);
     int S = 1;
     int64_t chunk = 0;
     if (dma) {   // one workgroup per CU: whole rounds of 256, >= 1024 positions each
@@ -2311,7 +2322,10 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
             a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
         }
     }
-    if (dma && a.log2nd >= 0) hipLaunchKernelGGL(wgrad_dma_kernel, dim3(tiles, S2), dim3(256), 0, stream, a);
+    if (dma && a.log2nd >= 0) {
+        if (tc.bd == 128) hipLaunchKernelGGL(wgrad_dma_kernel<2>, dim3(tiles, S2), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(tiles, S2), dim3(256), 0, stream, a);
+    }
     else if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 64) launch_wgrad<2, 1, 2, 2>(a, tiles, S2, stream);
@@ -2342,7 +2356,7 @@ int dcv_debug_kernel_info(char* buf, size_t n) {
         {"gather_dma<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, false, false>}, {"gather_dma<2,2,1,4>", (const void*)gather_gemm_dma_kernel<2, 2, 1, 4, false, false>},
         {"gather_dma<1,2,1,4>", (const void*)gather_gemm_dma_kernel<1, 2, 1, 4, false, false>}, {"gather_dma_patch<2,2,2,2>", (const void*)gather_gemm_dma_kernel<2, 2, 2, 2, false, true>},
         {"thin_gather", (const void*)thin_gather_kernel},
-        {"wgrad_dma", (const void*)wgrad_dma_kernel}, {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
+        {"wgrad_dma", (const void*)wgrad_dma_kernel<2>}, {"wgrad_dma64", (const void*)wgrad_dma_kernel<1>}, {"wgrad<2,2,2,2,R>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, true>}, {"wgrad<2,2,1,4,R>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, true>},
         {"wgrad<2,2,2,2>", (const void*)wgrad_gemm_kernel<2, 2, 2, 2, false>}, {"wgrad<2,1,2,2>", (const void*)wgrad_gemm_kernel<2, 1, 2, 2, false>},
         {"wgrad<2,2,1,4>", (const void*)wgrad_gemm_kernel<2, 2, 1, 4, false>}, {"wgrad<2,1,1,4>", (const void*)wgrad_gemm_kernel<2, 1, 1, 4, false>},
         {"wgrad<1,2,1,4>", (const void*)wgrad_gemm_kernel<1, 2, 1, 4, false>}, {"wgrad<1,1,1,4>", (const void*)wgrad_gemm_kernel<1, 1, 1, 4, false>},

@@ -51,6 +51,8 @@ CONVS = [
     ("conv2d_4s2p1_wgrad_dma", False, 2, 16, 128, 4, 2, 1, (16, 16), 9),
     ("convT2d_4s2p1_wgrad_dma", True, 2, 128, 8, 4, 2, 1, (8, 8), 21),
     ("conv3d_4s122_wgrad_dma", False, 3, 8, 128, 4, (1, 2, 2), (0, 1, 1), (6, 16, 16), 3),
+    ("conv2d_4s2p1_wgrad_dma64", False, 2, 16, 64, 4, 2, 1, (16, 16), 9),
+    ("conv3d_4s122_wgrad_dma64", False, 3, 32, 64, 4, (1, 2, 2), (0, 1, 1), (5, 8, 8), 4),
     # thin patch form (OC <= 4, >= 65536 positions): 3x3 heads, stride-2 stems' data gradients, 3-D depth-step
     ("convT2d_3s1p1_thin3", True, 2, 12, 3, 3, 1, 1, (64, 64), 16),
     ("conv2d_3s1p1_from1", False, 2, 1, 8, 3, 1, 1, (64, 64), 17),
