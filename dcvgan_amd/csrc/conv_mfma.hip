@@ -1125,6 +1125,72 @@ static void launch_thin_rows(const GatherArgs& a, int OC, int RC, dim3 grid, hip
     }
 }
 
+// --------------------------------------------------------------------------- //
+// widen_rows_kernel: the mirror case — at most 4 GATHERED channels, many output channels, 3x3 taps, unit stride,
+// 64-wide rows: the data gradient of the colour generator's RGB head (3 -> 128 at 64x64; 27 multiply-adds per
+// output, the MFMA path pads K = 27 to 32 and runs at the store rate of a 2.35 GB tensor).  A lane owns one
+// column and 4 output rows; the RC x 6 input rows with their DPP neighbours are read ONCE per workgroup into
+// registers, the packed weights of the whole op (27 x OC) into LDS, and the 4 waves walk the output channels:
+// 108 FMAs and 4 coalesced row stores per channel, no operand traffic in the loop.
+// --------------------------------------------------------------------------- //
+template <int RC>
+__global__ __launch_bounds__(256) void widen_rows_kernel(const GatherArgs a) {
+    extern __shared__ float wl[];   // [RC * 9][OCp] packed weights
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ohq = (uint32_t)a.OH >> 2;
+    const uint32_t plane = blockIdx.x / ohq;
+    const int oh0 = (int)(blockIdx.x - plane * ohq) * 4;
+    const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
+    for (int e = tid; e < RC * 9 * a.OCp; e += 256) wl[e] = a.wp[e];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base + a.td.delta[0]) * a.x_sd), 0, 0x80000000u, 0x00020000);
+    float v[RC][6][3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int ih = oh0 + a.p_ihmin + q;
+        const uint32_t vo = (unsigned)ih < (unsigned)a.th.size ? (uint32_t)(4 * (ih * a.x_sh + lane)) : 0x80000000u;
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc) {
+            const float c = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, rc * a.s_stepA, 0));
+            v[rc][q][1] = c;
+            v[rc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x138, 0xf, 0xf, true));   // column - 1
+            v[rc][q][2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, c), 0x130, 0xf, 0xf, true));   // column + 1
+        }
+    }
+    int perm[9];
+    {
+        typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+        const i32x16 sl16 = *reinterpret_cast<const i32x16*>(a.s_local);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) perm[t] = sl16[t];
+    }
+    __syncthreads();
+    const int OC = a.OC, OCp = a.OCp, act = a.act, accumulate = a.accumulate;
+    const float slope = a.slope;
+    float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)lane * a.y_sw;
+    for (int oc = wave; oc < OC; oc += 4) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc)
+#pragma unroll
+            for (int ra = 0; ra < 3; ++ra)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float w = wl[(rc * 9 + perm[ra * 3 + b]) * OCp + oc];   // wave-uniform address: LDS broadcast
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) o[p] += w * v[rc][p + ra][b];
+                }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float* q = yb + (int64_t)(oh0 + p) * a.y_sh + (int64_t)oc * a.y_sc;
+            float x = o[p];
+            if (accumulate) x += *q;
+            *q = apply_act(x, act, slope);
+        }
+    }
+}
+
 template <int T>
 static bool launch_thin_struct(const GatherArgs& a, int OC, int RC, int rc_per_split, dim3 grid, hipStream_t s) {
     switch (OC) {
@@ -2056,6 +2122,46 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             else launch_thin_rows<2, 2, 4, true, 0>(a, OC, RC, gr, stream);
             DCV_LAUNCH_CHECK();
             continue;
+        }
+        // <= 4 gathered channels, many output channels, 3x3 / unit stride / 64-wide rows: the register-resident form
+        if (tc.bn != 4 && RC <= 4 && KS2 == 1 && xd.sw == 1 && c.taps[0].n == 1 && c.taps[1].n == 3 && c.taps[2].n == 3 &&
+            c.taps[1].mul == 1 && c.taps[2].mul == 1 && c.o_ext[2] == 64 && c.taps[2].size == 64 && c.o_ext[1] % 4 == 0 &&
+            c.out_mul[1] == 1 && c.out_mul[2] == 1 && (size_t)RC * 9 * OCp * sizeof(float) <= 48 * 1024 && getenv("DCV_NO_WIDEN") == nullptr) {
+            auto span3 = [](const DimTaps& t, int* dmin) {
+                int lo = std::min(t.delta[0], std::min(t.delta[1], t.delta[2])), hi = std::max(t.delta[0], std::max(t.delta[1], t.delta[2]));
+                *dmin = lo;
+                return hi - lo == 2;
+            };
+            int dminh = 0, dminw = 0;
+            if (span3(c.taps[1], &dminh) && span3(c.taps[2], &dminw) && c.taps[2].base + dminw == -1) {
+                a.p_ihmin = c.taps[1].base + dminh;
+                a.s_stepA = (int32_t)(xd.sc * 4);
+                for (int ra = 0; ra < 3; ++ra)
+                    for (int b = 0; b < 3; ++b) {
+                        int uh = 0, uw = 0;
+                        for (int u = 0; u < 3; ++u) {
+                            if (c.taps[1].delta[u] - dminh == ra) uh = u;
+                            if (c.taps[2].delta[u] - dminw == b) uw = u;
+                        }
+                        a.s_local[ra * 3 + b] = uh * 3 + uw;
+                    }
+                if (npack > 0) {
+                    int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
+                    if (rcp != DCV_OK) return rcp;
+                    npack = 0;
+                    packmax = 0;
+                }
+                const dim3 gw((unsigned)(M64 / 256));
+                const size_t shm = (size_t)RC * 9 * OCp * sizeof(float);
+                switch (RC) {
+                    case 1: hipLaunchKernelGGL(widen_rows_kernel<1>, gw, dim3(256), shm, stream, a); break;
+                    case 2: hipLaunchKernelGGL(widen_rows_kernel<2>, gw, dim3(256), shm, stream, a); break;
+                    case 3: hipLaunchKernelGGL(widen_rows_kernel<3>, gw, dim3(256), shm, stream, a); break;
+                    default: hipLaunchKernelGGL(widen_rows_kernel<4>, gw, dim3(256), shm, stream, a); break;
+                }
+                DCV_LAUNCH_CHECK();
+                continue;
+            }
         }
         if (tc.bn == 4 && thin_struct) {
             const int rcps = KS2 > 1 ? kper * 16 / T : RC;   // whole channels per K split
