@@ -268,3 +268,47 @@ def test_fullwidth_scalars(dev):
             # generator-side norms are held to 1e-2, the discriminator-side ones (shallow) to 2e-3.
             tol = 1e-2 if n in ("ggen", "cgen") else 2e-3
             assert abs(p.grad.double().norm().item() - ref) < tol * max(ref, 1e-12), (n, k, p.grad.double().norm().item(), ref)
+
+
+def test_fullwidth_b16_against_the_oracle(dev):
+    """Real isogd-depth widths at B=16: large enough that every big-problem kernel variant is taken (row-reuse
+    thin kernels, patch staging, depth-step, fused BN statistics, both LDS-DMA weight-gradient tiles — the B=2
+    fixture above runs their small-problem / split-K alternatives).  Reference values: the pinned oracle on the
+    CPU, same weights and draws."""
+    from dcvgan_amd import trainer
+    from dcvgan_amd.configs import CONFIGS
+    B = 16
+    cfg = CONFIGS["isogd-depth"].scaled(batchsize=B)
+    torch.manual_seed(123)
+    models = trainer.build_models(cfg, torch.device("cpu"))
+    st = {n: {k: v.detach().clone() for k, v in m.state_dict().items()} for n, m in models.items()}
+    for n in st:
+        O.require_grad(st[n])
+    torch.manual_seed(321)
+    rng = O.TorchRng(); t = 7
+    xg_o = O.ggen_sample_videos(st["ggen"], B, 16, 40, 10, 1, rng, True)
+    xc_o = O.cgen_forward_videos(st["cgen"], xg_o, 10, rng, True)
+    yi_o = O.idis_forward(st["idis"], xg_o[:, :, t], xc_o[:, :, t], True, 0.1, rng, True)
+    yv_o = O.vdis_forward(st["vdis"], xg_o, xc_o, True, 0.1, rng, True)
+    yg_o = O.gdis_forward(st["gdis"], xg_o, xc_o, False, 0.2, rng, True)
+    loss_o = O.gen_loss("adversarial-loss", yi_o, yv_o, yg_o)
+    loss_o.backward()
+    for m in models.values():
+        m.to(dev)
+        for mod in m.modules():
+            if hasattr(mod, "device"):
+                mod.device = dev
+    share_rng(models, rng.log)
+    xg = models["ggen"].sample_videos(B); xc = models["cgen"].forward_videos(xg)
+    yi = models["idis"](xg[:, :, t], xc[:, :, t]); yv = models["vdis"](xg, xc); yg = models["gdis"](xg, xc)
+    assert G.relerr(xg.detach().cpu().numpy(), xg_o.detach().numpy()) < TOL and G.relerr(xc.detach().cpu().numpy(), xc_o.detach().numpy()) < TOL
+    for y, yo, k in ((yi, yi_o, "yi"), (yv, yv_o, "yv"), (yg, yg_o, "yg")):
+        assert G.relerr(y.detach().cpu().numpy(), yo.detach().numpy()) < TOL, k
+    v = trainer.build_loss(cfg).compute_gen_loss(yi, yv, yg)
+    assert abs(v.item() - loss_o.item()) < TOL * abs(loss_o.item())
+    v.backward()
+    for n, m in models.items():
+        for k, p in m.named_parameters():
+            ref = st[n][k].grad.double().norm().item()
+            tol = 1e-2 if n in ("ggen", "cgen") else 2e-3   # conditioning: see test_fullwidth_scalars
+            assert abs(p.grad.double().norm().item() - ref) < tol * max(ref, 1e-12), (n, k, p.grad.double().norm().item(), ref)
