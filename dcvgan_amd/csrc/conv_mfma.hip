@@ -1649,7 +1649,29 @@ struct DevTable {
 };
 
 static std::mutex g_plan_mu;
-static std::map<std::string, DevTable> g_tables;
+static std::map<std::string, DevTable> g_tables;   // keys start with the device ordinal: tables live on one device
+
+// A/B switches for tools/ (variant off when the variable is set); read once, not per call
+struct Toggles {
+    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64;
+    Toggles() {
+        auto on = [](const char* n) { return getenv(n) != nullptr; };
+        no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
+        no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64");
+    }
+};
+static const Toggles& toggles() {
+    static const Toggles t;
+    return t;
+}
+
+static std::string device_prefix() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    char b[16];
+    const int n = snprintf(b, sizeof(b), "d%d|", dev);
+    return std::string(b, n);
+}
 
 static int get_table(const std::string& key, const std::vector<KEntry>& host, DevTable* out) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -1801,7 +1823,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             const DimTaps& t0 = c.taps[0];
             const int nd = t0.n;
             if (tc.bn != 4 && (nd == 2 || nd == 4 || nd == 8) && c.taps[1].n * c.taps[2].n == 4 && RC % 4 == 0 && t0.mul == 1 &&
-                xd.sc * 16 < (1ll << 30) && xd.sd * 4 * nd < (1ll << 30) && getenv("DCV_NO_LDS_DMA") == nullptr && getenv("DCV_NO_DSTEP") == nullptr) {
+                xd.sc * 16 < (1ll << 30) && xd.sd * 4 * nd < (1ll << 30) && !toggles().no_lds_dma && !toggles().no_dstep) {
                 bool consecutive = true;
                 for (int u = 0; u < nd; ++u) consecutive = consecutive && t0.delta[u] == -u;
                 const bool padded = t0.base - (nd - 1) < 0 || c.o_ext[0] - 1 + t0.base >= t0.size;
@@ -1809,7 +1831,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
         }
         // ---- K table (cached) ----
-        std::string key(tag);
+        std::string key = device_prefix() + tag;
         {
             char buf[512];
             int nn = snprintf(buf, sizeof(buf), "|g%d|%d|%d|%lld|%lld|%d|%d|%lld|%lld|%lld|%lld|", (int)dstep, RC, OC, (long long)ws_o, (long long)ws_r, KH, KW,
@@ -1998,7 +2020,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
         }
         // ---- patch staging? (w-contiguous operand, whole output rows per tile, aligned 16-byte granules) ----
-        if (a.structured && tc.bn != 4 && getenv("DCV_NO_PATCH") == nullptr) {
+        if (a.structured && tc.bn != 4 && !toggles().no_patch) {
             const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n;
             int CH = 0;   // channels per K step; a step holds ONE depth tap
             if (a.structured == 2) CH = 4;
@@ -2045,7 +2067,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
         }
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
-        const bool dma = a.structured && tc.bn != 4 && getenv("DCV_NO_LDS_DMA") == nullptr;
+        const bool dma = a.structured && tc.bn != 4 && !toggles().no_lds_dma;
         if (!dma || KS2 > 1) stat_ok = false;   // only the LDS-DMA kernel's direct epilogue produces the sums
         if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
             int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
@@ -2077,7 +2099,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         int rows_kind = 0;   // 1: 3x3 @64   2: 2x2 @32   3: 2x2x4 @32
         int rows_iw0 = 0;
         if (tc.bn == 4 && KS2 == 1 && xd.sw == 1 && c.taps[0].mul == 1 && c.taps[1].mul == 1 && c.taps[2].mul == 1 &&
-            c.o_ext[2] == c.taps[2].size && getenv("DCV_NO_ROW64") == nullptr && xd.sc * 4 < (1ll << 30) && xd.sd * 4 * 8 < (1ll << 30)) {
+            c.o_ext[2] == c.taps[2].size && !toggles().no_row64 && xd.sc * 4 < (1ll << 30) && xd.sd * 4 * 8 < (1ll << 30)) {
             const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n, OWc = c.o_ext[2], OHc = c.o_ext[1];
             if (nd == 1 && nh == 3 && nw == 3 && OWc == 64 && OHc % 4 == 0) rows_kind = 1;
             else if (nd == 1 && nh == 2 && nw == 2 && OWc == 32 && OHc % 8 == 0) rows_kind = 2;
@@ -2126,7 +2148,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // <= 4 gathered channels, many output channels, 3x3 / unit stride / 64-wide rows: the register-resident form
         if (tc.bn != 4 && RC <= 4 && KS2 == 1 && xd.sw == 1 && c.taps[0].n == 1 && c.taps[1].n == 3 && c.taps[2].n == 3 &&
             c.taps[1].mul == 1 && c.taps[2].mul == 1 && c.o_ext[2] == 64 && c.taps[2].size == 64 && c.o_ext[1] % 4 == 0 &&
-            c.out_mul[1] == 1 && c.out_mul[2] == 1 && (size_t)RC * 9 * OCp * sizeof(float) <= 48 * 1024 && getenv("DCV_NO_WIDEN") == nullptr) {
+            c.out_mul[1] == 1 && c.out_mul[2] == 1 && (size_t)RC * 9 * OCp * sizeof(float) <= 48 * 1024 && !toggles().no_widen) {
             auto span3 = [](const DimTaps& t, int* dmin) {
                 int lo = std::min(t.delta[0], std::min(t.delta[1], t.delta[2])), hi = std::max(t.delta[0], std::max(t.delta[1], t.delta[2]));
                 *dmin = lo;
@@ -2326,7 +2348,7 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "%s: too many positions", tag);
     const int tiles = (DCp / tc.bd) * (Jp / tc.bj);
     // double-buffered LDS-DMA form: 128 x 128 tile, 4x4 inner taps, un-padded depth taps, full channel tiles
-    bool dma = getenv("DCV_NO_WGRAD_DMA") == nullptr && ((tc.bd == 128 && tc.bj == 128) || (tc.bd == 64 && tc.bj == 128 && getenv("DCV_NO_WGRAD_DMA64") == nullptr)) && k[1] == 4 && k[2] == 4 &&
+    bool dma = !toggles().no_wgrad_dma && ((tc.bd == 128 && tc.bj == 128) || (tc.bd == 64 && tc.bj == 128 && !toggles().no_wgrad_dma64)) && k[1] == 4 && k[2] == 4 &&
                (k[0] == 1 || k[0] == 2 || k[0] == 4 || k[0] == 8) && (k[0] == 1 || (p[0] == 0 && s[0] == 1)) &&
                DC % tc.bd == 0 && J % 128 == 0 && gd.sc * 4 < (1ll << 30) && dd.sc * 4 < (1ll << 30);
     int S = 1;
@@ -2355,7 +2377,7 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
 
     char kb[512];
     int nn = snprintf(kb, sizeof(kb), "%s|w|%d|%d,%d,%d|%lld|%lld|%lld|%lld", tag, GC, k[0], k[1], k[2], (long long)gd.sc, (long long)gd.sd, (long long)gd.sh, (long long)gd.sw);
-    std::string key(kb, nn);
+    std::string key = device_prefix() + std::string(kb, nn);
     DevTable tab;
     {
         std::lock_guard<std::mutex> lk(g_plan_mu);

@@ -496,16 +496,32 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(const float* __restrict__
 // ------------------------------------------------------------------------- //
 // Adam
 // ------------------------------------------------------------------------- //
+// torch.optim.Adam's single-tensor update, operation for operation (torch/optim/adam.py _single_tensor_adam):
+//   g' = g * gscale + wd * p ; m = lerp(m, g', 1 - b1) ; v = b2 * v + (1 - b2) * g' * g'
+//   p -= step_size * m / (sqrt(v) / bc2_sqrt + eps)
+// with the scalars (1 - b1, 1 - b2, step_size = lr / (1 - b1^t), bc2_sqrt) computed in double on the host and
+// rounded once, as Python does.  fp contraction is off for this file's Adam code path (see adam_update).
+struct AdamScalars {
+    float w1, b2, w2, eps, wd, step_size, bc2_sqrt, gscale;   // w1 = 1 - beta1, w2 = 1 - beta2
+};
+__device__ __forceinline__ void adam_update(float& pi, float gi, float& mi, float& vi, const AdamScalars& k) {
+#pragma clang fp contract(off)
+    gi = gi * k.gscale;
+    gi = gi + k.wd * pi;
+    // at::lerp: weight < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)
+    const float d = gi - mi;
+    mi = k.w1 < 0.5f ? mi + k.w1 * d : gi - d * (1.f - k.w1);
+    vi = vi * k.b2;
+    vi = vi + (k.w2 * gi) * gi;   // addcmul_(g, g, value): value * t1 * t2
+    const float denom = sqrtf(vi) / k.bc2_sqrt + k.eps;
+    pi = pi + (-k.step_size) * (mi / denom);
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                                   const AdamScalars k) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float pi = p[i];
-        const float gi = g[i] * gscale + wd * pi;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update(pi, g[i], mi, vi, k);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 
@@ -520,7 +536,7 @@ struct AdamPack {
     int64_t n[ADAM_MT];
     int32_t first_block[ADAM_MT + 1];   // prefix sum of the tensors' block counts (4096 elements per block)
 };
-__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamPack k, int nt, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamPack k, int nt, const AdamScalars sc) {
     int t = 0;
     while (t + 1 < nt && (int)blockIdx.x >= k.first_block[t + 1]) ++t;
     const int64_t base = (int64_t)((int)blockIdx.x - k.first_block[t]) * 4096;
@@ -533,13 +549,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamPack k, int n
     for (int e = 0; e < 16; ++e) {
         const int64_t i = base + e * 256 + threadIdx.x;
         if (i >= n) break;
-        const float pi = p[i];
-        const float gi = g[i] * gscale + wd * pi;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update(pi, g[i], mi, vi, sc);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 
@@ -1010,23 +1022,36 @@ int dcv_gan_loss(const float* y, int64_t n, int kind, float* loss_out, int accum
     return DCV_OK;
 }
 
-int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                  int step, float grad_scale, void* stream) {
+// bias corrections and step size in double, rounded once (torch computes them as Python floats)
+static AdamScalars adam_scalars(double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale) {
+    AdamScalars k;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    k.w1 = (float)(1.0 - beta1);
+    k.b2 = (float)beta2;
+    k.w2 = (float)(1.0 - beta2);
+    k.eps = (float)eps;
+    k.wd = (float)weight_decay;
+    k.step_size = (float)(lr / bc1);
+    k.bc2_sqrt = (float)sqrt(bc2);
+    k.gscale = (float)grad_scale;
+    return k;
+}
+
+int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  int step, double grad_scale, void* stream) {
     if (!p || !g || !m || !v || n < 0 || step < 1) return fail(DCV_EINVAL, "adam_step: bad arguments");
     if (n == 0) return DCV_OK;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+    const AdamScalars k = adam_scalars(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, k);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
 
 
 int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                        double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
     if (n_tensors < 0 || (n_tensors > 0 && (!p || !g || !m || !v || !numel)) || step < 1) return fail(DCV_EINVAL, "adam_step_multi: bad arguments");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    const AdamScalars sc = adam_scalars(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     for (int t0 = 0; t0 < n_tensors; t0 += ADAM_MT) {
         AdamPack k;
         memset(&k, 0, sizeof(k));
@@ -1040,7 +1065,7 @@ int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
         }
         k.first_block[nt] = blocks;
         if (blocks == 0) continue;
-        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), k, nt, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+        hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), k, nt, sc);
         DCV_LAUNCH_CHECK();
     }
     return DCV_OK;

@@ -76,8 +76,8 @@ _SIGS = {
     "dcv_gru_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dcv_gru_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dcv_gru_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
-    "dcv_adam_step_multi": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
-    "dcv_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
+    "dcv_adam_step_multi": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, _P]),
+    "dcv_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, _P]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -121,6 +121,10 @@ def _require(t: torch.Tensor, what: str):
         raise NativeError(f"{what}: expected a HIP device tensor, got {t.device} — the HIP path has no CPU fallback")
     if t.dtype != torch.float32:
         raise NativeError(f"{what}: expected float32, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's stream and the library's index tables live on it
+        raise NativeError(f"{what}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()} "
+                          "(one process per GPU: call torch.cuda.set_device first)")
 
 
 def dims5(t: torch.Tensor) -> Dims5:

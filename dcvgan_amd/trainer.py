@@ -46,11 +46,13 @@ def build_loss(cfg: StepConfig):
 
 
 def build_optimizers(cfg: StepConfig, models, data_parallel: bool = False):
-    """train.py:169-176."""
+    """train.py:169-176.  Data parallel: the optimisers stepped after the same backward share one gradient
+    bucket — D phase (trainer.py:319-322) and G phase (trainer.py:356-359) — so an iteration has two collectives."""
     opts = {}
+    buckets = {"D": optim.GradBucket(), "G": optim.GradBucket()} if data_parallel else None
     for name in MODEL_NAMES:
         o = optim.Adam(models[name].parameters(), lr=cfg.lr[name], betas=(0.5, 0.999), weight_decay=cfg.decay[name])
-        opts[name] = optim.DataParallelAdam(o) if data_parallel else o
+        opts[name] = optim.DataParallelAdam(o, buckets["D" if name.endswith("dis") else "G"]) if data_parallel else o
     return opts
 
 

@@ -194,12 +194,15 @@ int dcv_gru_backward(const float* dout, const float* e, const float* h0, const f
                      int T, int B, int dm, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- Adam (train.py:171-176: betas (0.5, 0.999), eps 1e-8, L2 weight decay) */
+/* torch.optim.Adam's update operation for operation; the bias corrections 1 - beta^step and the step size
+ * lr / (1 - beta1^step) are formed in double on the host (torch forms them as Python floats) and rounded once.
+ * g is scaled by grad_scale first (1 / world size under data parallelism, 1 otherwise). */
 int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                  float grad_scale, void* stream);
+                  double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                  double grad_scale, void* stream);
 /* the same update for n_tensors parameter tensors of one optimiser (one shared step count) in ceil(n/24) launches */
 int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+                        double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

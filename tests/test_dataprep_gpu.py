@@ -60,3 +60,42 @@ def test_surreal_depth(dev):
     got = dataprep.decode_surreal_depth(torch.from_numpy(depth).to(dev)).cpu().numpy()
     assert np.array_equal(got, want)
     assert got[0].min() == -1.0 and np.isclose(got[0][got[0] < 1.0].max(), 0.8)
+
+
+# --------------------------------------------------------------------------- #
+# pinned: outputs of the reference's own VideoDataset.__getitem__ (tests/golden/make_dataset_golden.py)
+# --------------------------------------------------------------------------- #
+def _fx():
+    from tests import goldenio as G
+    return G.load("dataset_norm.npz")
+
+
+def test_against_the_reference_dataset_class(dev):
+    """dataset.py:125-186 executed on the reference's mock dataset (+ a SURREAL-format one): same bytes."""
+    from dcvgan_amd import dataprep
+    fx = _fx()
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    n = 0
+    for i in range(3):   # mock: solid-colour PNG frames (test_dataset.py:63-95) — clips batched as a DataLoader would
+        got = dataprep.decode_color(up(fx[f"mock/{i}/color_in"][None])).cpu().numpy()[0]
+        assert got.dtype == np.float32 and np.array_equal(got, fx[f"mock/{i}/color_out"]); n += 1
+        got = dataprep.decode_depth(up(fx[f"mock/{i}/depth_in"][None])).cpu().numpy()[0]
+        assert np.array_equal(got, fx[f"mock/{i}/depth_out"]); n += 1
+    batch = np.stack([fx[f"mock/{i}/color_in"] for i in range(3)])
+    assert np.array_equal(dataprep.decode_color(up(batch)).cpu().numpy(), np.stack([fx[f"mock/{i}/color_out"] for i in range(3)]))
+    got = dataprep.decode_flow(up(fx["mock/0/flow_in"][None]), 64).cpu().numpy()[0]
+    assert np.array_equal(got, fx["mock/0/flow_out"]); n += 1
+    got = dataprep.decode_color(up(fx["surreal/0/color_in"][None])).cpu().numpy()[0]
+    assert np.array_equal(got, fx["surreal/0/color_out"]); n += 1
+    # SURREAL depth: a person, a flat foreground (max == min), no background, no foreground — one batch
+    depth = np.stack([fx[f"surreal/{i}/depth_in"] for i in range(4)])
+    got = dataprep.decode_surreal_depth(up(depth)).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], fx[f"surreal/{i}/depth_out"]), i
+        n += 1
+    segm = np.stack([fx[f"surreal/{i}/segm_in"] for i in range(4)])
+    got = dataprep.decode_segmentation(up(segm)).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], fx[f"surreal/{i}/segm_out"]), i
+        n += 1
+    assert n == 16

@@ -1,6 +1,6 @@
-"""CPU, world_size 2 over gloo: the data-parallel optimiser wrapper averages gradients across ranks
-before the inner step (one collective per backward, also for the trainer's double ggen step), and
-broadcast_module makes replicas identical."""
+"""CPU, world_size 2 over gloo: the data-parallel optimiser wrappers of one phase share a gradient bucket that is
+all-reduced once per backward (explicit dirty flag set by autograd hooks — also for the trainer's double ggen
+step, for accumulated backwards and for gated-off updates), and broadcast_module makes replicas identical."""
 import os
 import socket
 
@@ -32,31 +32,62 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dcvgan_amd import optim
     torch.manual_seed(100 + rank)                       # deliberately different replicas
-    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
-    optim.broadcast_module(net)                         # -> rank 0's parameters and buffers everywhere
-    w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
-    frozen = list(net.parameters())[-1]                 # a parameter that gets no gradient
-    opt = optim.DataParallelAdam(_SGD(net.parameters(), 0.1), bucket_bytes=64)   # tiny buckets: several collectives
-    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(rank))
-    y = net(x)[:, :2].sum() * (rank + 1)
-    y.backward()
-    frozen.grad = None
-    local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
-    opt.step(); opt.step()                              # second step must NOT reduce again
-    gathered = [None] * world
-    dist.all_gather_object(gathered, [None if g is None else g.numpy() for g in local])
-    summed = [p.grad.clone() if p.grad is not None else None for p in net.parameters()]
-    w1 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    netA = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    netB = torch.nn.Linear(3, 2)
+    for n in (netA, netB):
+        optim.broadcast_module(n)                       # -> rank 0's parameters and buffers everywhere
+    params = list(netA.parameters()) + list(netB.parameters())
+    w0 = torch.cat([p.detach().reshape(-1) for p in params])
+    frozen = list(netA.parameters())[-1]                # a parameter that gets no gradient
+    # two optimisers stepped after the same backward share ONE bucket (tiny chunks: several collectives per reduction)
+    bucket = optim.GradBucket(bucket_bytes=64)
+    optA = optim.DataParallelAdam(_SGD(netA.parameters(), 0.1), bucket)
+    optB = optim.DataParallelAdam(_SGD(netB.parameters(), 0.1), bucket)
+    ok = True
+
+    def run(scale):
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(rank))
+        (netB(netA(x)).sum() * (rank + 1) * scale).backward()
+        frozen.grad = None
+
+    def check_sum(local):
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [None if g is None else g.numpy() for g in local])
+        good = True
+        for i, p in enumerate(params):
+            if p.grad is None:
+                good &= local[i] is None
+                continue
+            want = sum(torch.from_numpy(g[i]) for g in gathered)
+            good &= torch.allclose(p.grad, want, atol=1e-6)   # grads hold the SUM; 1/world is the step's grad_scale
+        return good
+
+    # iteration 1: one backward, then A.step, B.step, A.step (the trainer's ggen / cgen / ggen pattern)
+    run(1.0)
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    ok &= bucket.dirty
+    optA.step()
+    ok &= bucket.reductions == 1 and not bucket.dirty
+    optB.step(); optA.step()                            # same backward: must NOT reduce again
+    ok &= bucket.reductions == 1 and check_sum(local)
+    ok &= optA.inner.grad_scale == 1.0 / world and optA.inner.steps == 2 and optB.inner.steps == 1
+    # iteration 2: zero_grad, TWO backwards accumulated (D phase: real + fake), one reduction of the sum
+    for n in (netA, netB):
+        n.zero_grad()
+    run(1.0); run(0.5)
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    optB.step()                                         # whichever member steps first reduces the whole bucket
+    ok &= bucket.reductions == 2 and check_sum(local)
+    optA.step()
+    ok &= bucket.reductions == 2
+    # iteration 3: no backward at all (update gated off) -> a step must not start a collective
+    optA.step()
+    ok &= bucket.reductions == 2
+    w1 = torch.cat([p.detach().reshape(-1) for p in params])
     allw = [None] * world
     dist.all_gather_object(allw, (w0.numpy(), w1.numpy()))
-    ok = True
-    for i, s in enumerate(summed):
-        if s is None:
-            continue
-        want = sum(torch.from_numpy(g[i]) for g in gathered)
-        ok &= torch.allclose(s, want, atol=1e-6)          # grads hold the SUM; 1/world is the step's grad_scale
-    ok &= opt.inner.grad_scale == 1.0 / world and opt.inner.steps == 2
     ok &= all((a[0] == allw[0][0]).all() and (a[1] == allw[0][1]).all() for a in allw)   # replicas stay identical
+    ok &= not (w0 == w1).all()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

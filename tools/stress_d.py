@@ -1,0 +1,36 @@
+"""32 x 128 x 128 discriminator stress shape (SURVEY §8(d) "D5"): vdis + gdis forward/backward on flow clips
+(Cg = 2), HIP-event timed.  Usage: python tools/stress_d.py [B]"""
+import sys
+sys.path.insert(0, '.')
+import torch
+from dcvgan_amd import discriminator as D, native
+
+native.lib()
+dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+torch.manual_seed(0)
+vdis = D.VideoDiscriminator(2, 3, True, 0.2, 64).to(dev)
+gdis = D.GradientDiscriminator(2, 3, False, 0.2, 32).to(dev)
+xc = (torch.rand(B, 3, 32, 128, 128, device=dev) * 2 - 1).requires_grad_(True)
+xg = (torch.rand(B, 2, 32, 128, 128, device=dev) - 0.5).requires_grad_(True)
+
+
+def step():
+    for m in (vdis, gdis):
+        m.zero_grad()
+    yv, yg = vdis(xg, xc), gdis(xg, xc)
+    (yv.mean() + yg.mean()).backward()
+    return yv, yg
+
+
+yv, yg = step()
+torch.cuda.synchronize()
+print("shapes", tuple(yv.shape), tuple(yg.shape), "finite", bool(torch.isfinite(yv).all() and torch.isfinite(yg).all()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3):
+    step()
+e1.record(); e1.synchronize()
+ms = e0.elapsed_time(e1) / 3
+gf = 3 * (55.1 + 13.6) * B   # fwd + dgrad + wgrad, SURVEY §8(d)
+print(f"B={B}: {ms:.2f} ms per fwd+bwd, ~{gf / ms:.1f} TFLOP/s, peak mem {torch.cuda.max_memory_allocated() / 1e9:.2f} GB")
