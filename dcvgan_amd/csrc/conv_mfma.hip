@@ -1785,22 +1785,31 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                       int RC, int OC, int64_t ws_o, int64_t ws_r, int KH, int KW,
                       const std::vector<GatherClass>& classes, int act, float slope, int accumulate,
                       void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
-                      float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr) {
+                      float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, const dcv_wpack* pack = nullptr) {
     const TileCfg tc = pick_gather_tile(OC);
+    // packed weights: in the caller's buffer when one is given (and already valid when pack->ready), else in `ws`
+    char* const pk_base = pack && pack->buf ? reinterpret_cast<char*>(pack->buf) : nullptr;
+    const bool pk_ready = pk_base && pack->ready;
+    size_t pk_off = 0;
     const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
     // fused BatchNorm partial sums (forward only): one row of {sum, sum^2} per (class, position tile)
     int stat_ntm = 0, stat_ncls = 0, stat_ci = 0;
     bool stat_ok = stat != nullptr && act == DCV_ACT_NONE && !accumulate && tc.bn != 4;
     if (stat_ok) {
+        int ntm_min = INT32_MAX;
         for (const GatherClass& c : classes) {
             if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
             const int64_t Mc = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
-            stat_ntm = std::max<int>(stat_ntm, (int)((Mc + tc.bm - 1) / tc.bm));
+            const int ntm = (int)((Mc + tc.bm - 1) / tc.bm);
+            stat_ntm = std::max<int>(stat_ntm, ntm);
+            ntm_min = std::min<int>(ntm_min, ntm);
             ++stat_ncls;
         }
         const size_t need = (size_t)stat_ncls * stat_ntm * OCp * 2 * sizeof(float);
         if (need == 0 || need > stat_bytes) stat_ok = false;
-        else DCV_HIP_CHECK(hipMemsetAsync(stat, 0, need, stream));
+        // every (class, position tile) row is written by exactly one workgroup when the classes have the same tile
+        // count (the usual case); only ragged classes leave rows that must read as zero
+        else if (ntm_min != stat_ntm) DCV_HIP_CHECK(hipMemsetAsync(stat, 0, need, stream));
     }
     if (stat_parts) *stat_parts = 0;
     size_t ws_off = 0;
@@ -1897,16 +1906,27 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // ---- pack weights ----
         const size_t wp_bytes = align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
         const size_t slab_bytes = KS2 > 1 ? align_up((size_t)KS2 * OCp * Mp * sizeof(float), 256) : 0;
-        if (ws_off + wp_bytes + slab_bytes > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, ws_off + wp_bytes + slab_bytes, ws_bytes);
-        float* wp = reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off);
-        ws_off += wp_bytes;
+        float* wp;
+        if (pk_base) {
+            if (pk_off + wp_bytes > pack->bytes) return fail(DCV_EWORKSPACE, "%s: packed-weight buffer too small (%zu needed, %zu given)", tag, pk_off + wp_bytes, pack->bytes);
+            wp = reinterpret_cast<float*>(pk_base + pk_off);
+            pk_off += wp_bytes;
+        } else {
+            if (ws_off + wp_bytes > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, ws_off + wp_bytes, ws_bytes);
+            wp = reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off);
+            ws_off += wp_bytes;
+        }
+        if (ws_off + slab_bytes > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, ws_off + slab_bytes, ws_bytes);
         float* slab = KS2 > 1 ? reinterpret_cast<float*>(static_cast<char*>(ws) + ws_off) : nullptr;
         ws_off += slab_bytes;
-        packs.ktab[npack] = tab.dev;
-        packs.wp[npack] = wp;
-        packs.K16[npack] = KIT * 16;
-        if (KIT * 16 > packmax) packmax = KIT * 16;
-        if (++npack == 4) {
+        if (!pk_ready) {
+            packs.ktab[npack] = tab.dev;
+            packs.wp[npack] = wp;
+            packs.K16[npack] = KIT * 16;
+            if (KIT * 16 > packmax) packmax = KIT * 16;
+            ++npack;
+        }
+        if (npack == 4) {
             int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
             if (rcp != DCV_OK) return rcp;
             npack = 0;
@@ -2234,6 +2254,19 @@ static size_t gather_ws_bytes(int RC, int OC, int N, const std::vector<GatherCla
     return tot + 256;
 }
 
+static size_t gather_pack_bytes(int RC, int OC, const std::vector<GatherClass>& classes) {
+    const TileCfg tc = pick_gather_tile(OC);
+    const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
+    size_t tot = 0;
+    for (const GatherClass& c : classes) {
+        const int T = c.taps[0].n * c.taps[1].n * c.taps[2].n;
+        if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+        const int KIT = (int)(((int64_t)RC * T + 15) / 16);
+        tot += align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
+    }
+    return tot;
+}
+
 // "direct" relation: gathered position = o*stride - pad + k  (conv fprop, convT dgrad)
 static std::vector<GatherClass> direct_classes(const int k[3], const int s[3], const int p[3], const int o_ext[3], const int in_ext[3]) {
     GatherClass c;
@@ -2519,7 +2552,8 @@ uint64_t dcv_launch_count(void) { return g_launches.load(); }
 static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, const dcv_dims5* xd, const float* w,
                          float* out, const dcv_dims5* yd, int act, float slope, int accumulate,
                          void* ws, size_t ws_bytes, void* stream, size_t* need_only,
-                         float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr) {
+                         float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr,
+                         const dcv_wpack* pack = nullptr, size_t* pack_need = nullptr) {
     // xd = module input dims, yd = module output dims, always.
     int rc = check_geom(g, xd, yd, "conv");
     if (rc != DCV_OK) return rc;
@@ -2565,6 +2599,10 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
             *stat_need = (size_t)(ncls * ntm * OCp * 2) * sizeof(float);
             return DCV_OK;
         }
+        if (pack_need) {
+            *pack_need = gather_pack_bytes(RC, OC, cls);
+            return DCV_OK;
+        }
         if (need_only) {
             *need_only = gather_ws_bytes(RC, OC, dst.n, cls);
             return DCV_OK;
@@ -2572,7 +2610,7 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
         if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
         return run_gather(a_, src, out, dst, w, RC, OC, ws_o, ws_r, k[1], k[2], cls, act, slope, accumulate, ws, ws_bytes, st,
                           which == 0 ? (g->transposed ? "convT_fwd" : "conv_fwd") : (g->transposed ? "convT_bwd_data" : "conv_bwd_data"),
-                          stat, stat_bytes, stat_parts);
+                          stat, stat_bytes, stat_parts, pack);
     }
     return fail(DCV_EINVAL, "conv: bad dispatch");
 }
@@ -2591,9 +2629,16 @@ size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, cons
     return need;
 }
 
+size_t dcv_conv_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
+    size_t need = 0;
+    if (which != 0 && which != 1) return 0;
+    if (conv_dispatch(which, g, nullptr, x, nullptr, nullptr, y, 0, 0.f, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, &need) != DCV_OK) return 0;
+    return need;
+}
+
 int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
-                     int act, float slope, void* ws, size_t ws_bytes, void* stream) {
-    return conv_dispatch(0, g, x, xd, w, y, yd, act, slope, 0, ws, ws_bytes, stream, nullptr);
+                     int act, float slope, const dcv_wpack* pack, void* ws, size_t ws_bytes, void* stream) {
+    return conv_dispatch(0, g, x, xd, w, y, yd, act, slope, 0, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pack);
 }
 
 size_t dcv_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y) {
@@ -2603,16 +2648,16 @@ size_t dcv_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dc
 }
 
 int dcv_conv_forward_stats(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
-                           float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream) {
+                           float* stat, size_t stat_bytes, int* nparts, int* pitch, const dcv_wpack* pack, void* ws, size_t ws_bytes, void* stream) {
     if (!stat || !nparts || !pitch) return fail(DCV_EINVAL, "conv_forward_stats: null pointer");
     const TileCfg tc = pick_gather_tile(yd ? yd->c : 1);
     *pitch = yd ? (yd->c + tc.bn - 1) / tc.bn * tc.bn : 0;
-    return conv_dispatch(0, g, x, xd, w, y, yd, DCV_ACT_NONE, 0.f, 0, ws, ws_bytes, stream, nullptr, stat, stat_bytes, nparts);
+    return conv_dispatch(0, g, x, xd, w, y, yd, DCV_ACT_NONE, 0.f, 0, ws, ws_bytes, stream, nullptr, stat, stat_bytes, nparts, nullptr, pack);
 }
 
 int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd,
-                           int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    return conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream, nullptr);
+                           int accumulate, const dcv_wpack* pack, void* ws, size_t ws_bytes, void* stream) {
+    return conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pack);
 }
 
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd,

@@ -329,27 +329,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(ChanMap m, const float* _
     if (threadIdx.x == 0) { partial[(int64_t)blockIdx.x * 2] = acc[0]; partial[(int64_t)blockIdx.x * 2 + 1] = acc[1]; }
 }
 
-// partial[c] = {sum, sum^2} in fp64 from the conv epilogue's per-tile fp32 sums stat[part][pitch][2]
-__global__ __launch_bounds__(256) void bn_partials_kernel(const float* __restrict__ stat, int nparts, int pitch, double* __restrict__ partial) {
-    __shared__ double red[8];
-    const int c = blockIdx.x;
-    double acc[2] = {0.0, 0.0};
-    for (int p = threadIdx.x; p < nparts; p += 256) {
-        const float2 v = *reinterpret_cast<const float2*>(stat + ((int64_t)p * pitch + c) * 2);
-        acc[0] += (double)v.x;
-        acc[1] += (double)v.y;
-    }
-    block_sum<2>(acc, red);
-    if (threadIdx.x == 0) { partial[(int64_t)c * 2] = acc[0]; partial[(int64_t)c * 2 + 1] = acc[1]; }
-}
-
-__global__ void bn_finalize_kernel(const double* __restrict__ partial, int C, int split, double count, float eps, float momentum,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0, s1 = 0;
-    for (int k = 0; k < split; ++k) { s0 += partial[((int64_t)c * split + k) * 2]; s1 += partial[((int64_t)c * split + k) * 2 + 1]; }
+__device__ __forceinline__ void bn_finalize_channel(int c, double s0, double s1, double count, float eps, float momentum,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var) {
     const double mean = s0 / count;
     double var = s1 / count - mean * mean;
     if (var < 0) var = 0;
@@ -359,6 +341,38 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partial, int C, in
         const double unbiased = count > 1 ? var * count / (count - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// `nbt`: the module's num_batches_tracked buffer (int64, may be NULL), bumped here instead of by a launch of its own
+__global__ void bn_finalize_kernel(const double* __restrict__ partial, int C, int split, double count, float eps, float momentum,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < split; ++k) { s0 += partial[((int64_t)c * split + k) * 2]; s1 += partial[((int64_t)c * split + k) * 2 + 1]; }
+    bn_finalize_channel(c, s0, s1, count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+}
+
+// conv -> BatchNorm pairs: {sum, sum^2} in fp64 from the conv epilogue's per-tile fp32 sums stat[part][pitch][2], finalised
+// in the same launch (one block per channel)
+__global__ __launch_bounds__(256) void bn_partials_finalize_kernel(const float* __restrict__ stat, int nparts, int pitch, double count, float eps, float momentum,
+                                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                                   float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* __restrict__ nbt) {
+    __shared__ double red[8];
+    const int c = blockIdx.x;
+    double acc[2] = {0.0, 0.0};
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(stat + ((int64_t)p * pitch + c) * 2);
+        acc[0] += (double)v.x;
+        acc[1] += (double)v.y;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        if (c == 0 && nbt) *nbt += 1;
+        bn_finalize_channel(c, acc[0], acc[1], count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
     }
 }
 
@@ -397,6 +411,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(ChanMap m, const flo
     int64_t g1 = g0 + m.seg;
     if (g1 > m.per_chan) g1 = m.per_chan;
     const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    // the activation's branch is decided by EXACTLY the expression the forward pass evaluated (BnApply): a
+    // pre-activation within rounding of zero must not come out positive there and non-positive here
+    const float sc = ga * is, sh = be - mu * sc;
     float a0 = 0.f, a1 = 0.f;
     double acc[2] = {0.0, 0.0};
     int cnt = 0;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(ChanMap m, const flo
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const float xh = (v[i] - mu) * is;
-            const float z = (ga * xh + be) * mk;
+            const float z = (v[i] * sc + sh) * mk;
             float dz = d[i] * mk;
             if (act == DCV_ACT_LEAKY) dz *= (z > 0.f ? 1.f : slope);
             else if (act == DCV_ACT_TANH) { const float t = tanhf(z); dz *= 1.f - t * t; }
@@ -447,10 +464,11 @@ struct BnBwdApply {
         const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
         const float mk = mask ? mask[(int64_t)p.n * m.C + c] : 1.f;
         const float k0 = training ? coef[2 * c] : 0.f, k1 = training ? coef[2 * c + 1] : 0.f;
+        const float sc = ga * is, sh = be - mu * sc;   // as in BnApply: same branch of the activation as the forward pass
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const float xh = (v[i] - mu) * is;
-            const float z = (ga * xh + be) * mk;
+            const float z = (v[i] * sc + sh) * mk;
             float dz = d[i] * mk;
             if (act == DCV_ACT_LEAKY) dz *= (z > 0.f ? 1.f : slope);
             else if (act == DCV_ACT_TANH) { const float t = tanhf(z); dz *= 1.f - t * t; }
@@ -937,7 +955,7 @@ int dcv_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t of
 }
 
 int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* mask,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, const float* mask,
                        int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !same_shape(*xd, *yd)) return fail(DCV_EINVAL, "bn_act_forward: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -954,7 +972,7 @@ int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_
         else hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(C * cm.split), dim3(256), 0, s, cm, x, rv(*xd), partial);
         DCV_LAUNCH_CHECK();
         const double count = (double)xd->n * xd->d * xd->h * xd->w;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, cm.split, count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, cm.split, count, eps, momentum, save_mean, save_invstd, running_mean, running_var, num_batches_tracked);
         DCV_LAUNCH_CHECK();
     } else {
         if (!running_mean || !running_var) return fail(DCV_EINVAL, "bn_act_forward: eval mode needs running stats");
@@ -966,7 +984,7 @@ int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_
 }
 
 int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* mask,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, const float* mask,
                              float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch,
                              void* ws, size_t ws_bytes, void* stream) {
     if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !stat || nparts < 1 || !same_shape(*xd, *yd) || pitch < xd->c)
@@ -977,12 +995,10 @@ int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, cons
     const void* ptrs[2] = {x, y};
     RowMap m = make_rowmap(*xd, views, 2, ptrs);
     if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
-    if (ws_bytes < dcv_bn_workspace_bytes(C) || !ws) return fail(DCV_EWORKSPACE, "bn_act_forward_stats: workspace too small");
-    double* partial = static_cast<double*>(ws);
-    hipLaunchKernelGGL(bn_partials_kernel, dim3(C), dim3(256), 0, s, stat, nparts, pitch, partial);
-    DCV_LAUNCH_CHECK();
+    (void)ws; (void)ws_bytes;
     const double count = (double)xd->n * xd->d * xd->h * xd->w;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, C, 1, count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3(C), dim3(256), 0, s, stat, nparts, pitch, count, eps, momentum, save_mean, save_invstd, running_mean, running_var,
+                       num_batches_tracked);
     DCV_LAUNCH_CHECK();
     BnApply f{x, y, rv(*xd), rv(*yd), gamma, beta, save_mean, save_invstd, mask, act, slope};
     return launch_ew(m, f, s);

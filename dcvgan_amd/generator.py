@@ -123,8 +123,8 @@ class Outconv(nn.Module):
         self.main = nn.Sequential(_convT(in_ch, out_ch, 3, 1, 1), nn.Tanh())
 
 
-def _block_forward(self, x, rng=None, out=None):
-    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out)
+def _block_forward(self, x, rng=None, out=None, grad_slot=None):
+    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out, grad_slot=grad_slot)
 
 
 for _cls in (Inconv, DownBlock, UpBlock, Outconv):
@@ -172,7 +172,7 @@ class ColorVideoGenerator(nn.Module):
         skips = [self.inconv(x, rng, out=bufs[0].second)]
         for k, blk in enumerate(self.down_blocks):
             dst = bufs[k + 1].second if k + 1 < 6 else bufs[6].first
-            skips.append(blk(skips[-1], rng, out=dst))
+            skips.append(blk(skips[-1], rng, out=dst, grad_slot=bufs[k].slot))   # skips[k] lives in bufs[k].second
         zc = ops.copy_into(z, bufs[6].second)
         h = bufs[6].join(skips[6], zc)
         for i, blk in enumerate(self.up_blocks):

@@ -21,6 +21,15 @@ from . import ops
 import os
 
 _FUSE_BN_STATS = os.environ.get("DCV_NO_BN_FUSION") is None
+# Test instrumentation: when a list is installed here, every fused (Leaky)ReLU appends the branch pattern `y > 0` of
+# its output, in execution order — the pattern the backward kernels differentiate with (tests/test_fullwidth_gpu.py
+# replays it in an fp64 evaluation of the same graph on the host).  None in production: nothing is recorded.
+KINK_TAP = None
+
+
+def _tap(y, fused):
+    if KINK_TAP is not None and fused is not None and fused[0] == ops.ACT_LEAKY:
+        KINK_TAP.append((y.detach() > 0).cpu())
 _CONVS = (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)
 _BNS = (nn.BatchNorm2d, nn.BatchNorm3d)
 
@@ -51,15 +60,16 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, part
     mask = None
     if dropout is not None and dropout.training:
         mask = rng.dropout2d_mask(x.shape[0], x.shape[1], dropout.p, x.device)
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    # num_batches_tracked is bumped by the statistics kernel itself (one launch less per BatchNorm layer)
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
-                      bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, partials=partials if training else None)
+                      bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, partials=partials if training else None,
+                      num_batches_tracked=bn.num_batches_tracked if training else None)
 
 
-def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
+def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None) -> torch.Tensor:
     """`out`: destination view for the sequence's LAST fused op (a concat-buffer slice), when that
-    op is a conv(+act) or a BatchNorm group."""
+    op is a conv(+act) or a BatchNorm group.  `grad_slot`: ops.GradSlot of the concat buffer that holds x
+    (x is a skip tensor): passed to the FIRST convolution, whose data gradient then accumulates into it."""
     layers = list(seq)
     i, n = 0, len(layers)
     pending = None   # BatchNorm partial sums left by the conv that produced x (conv -> BN pairs in training mode)
@@ -69,11 +79,12 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
         if isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None
             if fused is not None:
-                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None)
+                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None, grad_slot=grad_slot if i == 0 else None)
+                _tap(x, fused)
                 i += 2
             else:
                 box = [] if (isinstance(nxt, _BNS) and nxt.training and _FUSE_BN_STATS) else None
-                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None, bn_stats=box)
+                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None, bn_stats=box, grad_slot=grad_slot if i == 0 else None)
                 pending = box[0] if box else None
                 i += 1
         elif isinstance(layer, _BNS):
@@ -86,11 +97,13 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None) -> torch.Tensor:
             if fused is not None:
                 j += 1
             x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop, out=out if j >= n else None, partials=pending)
+            _tap(x, fused)
             pending = None
             i = j
         elif _act_of(layer) is not None:
             code, slope = _act_of(layer)
             x = ops.act(x, code, slope)
+            _tap(x, (code, slope))
             i += 1
         elif hasattr(layer, "use_noise") and hasattr(layer, "sigma"):  # discriminator.Noise
             if layer.use_noise:

@@ -29,6 +29,11 @@ class Dims5(C.Structure):
                 ("sn", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
 
 
+class WPack(C.Structure):
+    """dcv_wpack: caller-owned K-major packed weights of one (layer, pass, input geometry)."""
+    _fields_ = [("buf", C.c_void_p), ("bytes", C.c_size_t), ("ready", C.c_int32)]
+
+
 class ConvGeom(C.Structure):
     _fields_ = [("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
@@ -48,14 +53,15 @@ _SIGS = {
     "dcv_launch_count": (C.c_uint64, []),
     "dcv_debug_kernel_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dcv_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
-    "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_conv_packed_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
+    "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
     "dcv_conv_stats_bytes": (C.c_size_t, [_G, _D, _D]),
-    "dcv_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t, _P]),
-    "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _P, C.c_size_t, _P]),
+    "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
     "dcv_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "dcv_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),
-    "dcv_bn_act_forward_stats": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_bn_act_forward_stats": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "dcv_bn_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "dcv_act_forward": (C.c_int, [_P, _D, _P, _D, C.c_int, C.c_float, _P]),
     "dcv_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, C.c_int, C.c_float, _P]),

@@ -97,13 +97,54 @@ def _dest(out, shape, device):
     return t.detach()  # fresh tensor object sharing the memory; becomes the op's output
 
 
+class _PackCache:
+    """Packed (K-major) weights of one weight tensor, owned on this side of the ABI (dcv_wpack): one buffer per
+    (pass, geometry, input layout), valid while the tensor's autograd version and storage stay what they were when it
+    was packed.  Every in-place change bumps the version — load_state_dict / init through torch, the HIP Adam through
+    torch.autograd.graph.increment_version (optim.Adam.step) — so a layer that runs 2-3 times between optimiser steps
+    (D on real and fake batches, trainer.py:299-309,347-349) is packed once.  Lives in `weight._dcv_pack`: it dies
+    with the tensor object, so recycled addresses cannot alias."""
+    __slots__ = ("entries",)
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, w, which, g, xd_t, yd_t, xd, yd):
+        key = (which, g.key(), tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
+        e = self.entries.get(key)
+        stamp = (w._version, w.data_ptr())
+        if e is None:
+            nbytes = lib().dcv_conv_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), which)
+            if nbytes == 0:
+                return None
+            e = self.entries[key] = [None, torch.empty(nbytes, dtype=torch.uint8, device=w.device)]
+        ready = e[0] == stamp
+        e[0] = stamp
+        return N.WPack(e[1].data_ptr(), e[1].numel(), int(ready))
+
+
+_USE_PACK_CACHE = os.environ.get("DCV_NO_PACK_CACHE") is None
+_SKIP_ACCUMULATE = os.environ.get("DCV_NO_SKIP_ACCUMULATE") is None
+
+
+def _pack_of(w):
+    if not _USE_PACK_CACHE:
+        return None
+    pc = getattr(w, "_dcv_pack", None)
+    if pc is None:
+        pc = w._dcv_pack = _PackCache()
+    return pc
+
+
 class _Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
+        ctx.grad_slot = grad_slot
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
-        w = w.contiguous()
+        if not w.is_contiguous():
+            raise N.NativeError("conv: weights must be contiguous (torch layout)")
         y = _dest(out, _out_shape(g, x), x.device)
         xd, yd = dims5(x), dims5(y)
         L = lib()
@@ -111,17 +152,20 @@ class _Conv(Function):
         if need == 0:
             raise N.NativeError("conv forward: " + L.dcv_last_error().decode())
         wsp, wsn = _ws("conv", need, x.device)
+        ctx.pack = pc = _pack_of(w)
+        pk = pc.get(w, 0, g, x, y, xd, yd) if pc is not None else None
+        pkp = C.byref(pk) if pk is not None else None
         sbytes = L.dcv_conv_stats_bytes(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE) else 0
         if sbytes:
             # conv -> BatchNorm pair: the epilogue leaves per-tile {sum, sum^2} of y, the BN op skips its pass over y
             stat = torch.empty(sbytes // 4, dtype=torch.float32, device=x.device)
             nparts, pitch = C.c_int(0), C.c_int(0)
             check(L.dcv_conv_forward_stats(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), ptr(stat), sbytes,
-                                           C.byref(nparts), C.byref(pitch), wsp, wsn, stream_ptr()), "dcv_conv_forward_stats")
+                                           C.byref(nparts), C.byref(pitch), pkp, wsp, wsn, stream_ptr()), "dcv_conv_forward_stats")
             if nparts.value > 0:
                 bn_stats.append((stat, nparts.value, pitch.value))
         else:
-            check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_conv_forward")
+            check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, pkp, wsp, wsn, stream_ptr()), "dcv_conv_forward")
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -140,23 +184,33 @@ class _Conv(Function):
         xd, dyd = dims5(x), dims5(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _empty(x.shape, x.device)
+            # x is a U-Net skip tensor whose OTHER consumer (the concat) has already delivered its gradient slice:
+            # add this data gradient into that slice in the GEMM epilogue and hand autograd nothing to sum
+            # (replaces a strided torch add over the tensor; the slice object is the one autograd holds)
+            slot = ctx.grad_slot
+            into = slot.take(x) if slot is not None else None
+            dx = into if into is not None else _empty(x.shape, x.device)
             dxd = dims5(dx)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1)
             wsp, wsn = _ws("conv", need, x.device)
-            check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), 0, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
+            pk = ctx.pack.get(w, 1, g, dx, dy, dxd, dyd) if ctx.pack is not None else None
+            check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), int(into is not None),
+                                           C.byref(pk) if pk is not None else None, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
+            if into is not None:
+                dx = None
         if ctx.needs_input_grad[1]:
             dw = _empty(w.shape, w.device)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None):
     """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries.
-    `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into."""
-    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats)
+    `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into.
+    `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection), see GradSlot."""
+    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot)
 
 
 # --------------------------------------------------------------------------- #
@@ -165,7 +219,7 @@ def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, b
 class _BnAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float, out=None,
-                partials=None):
+                partials=None, nbt=None):
         N._require(x, "bn input")
         L = lib()
         Cn = x.shape[1]
@@ -175,12 +229,12 @@ class _BnAct(Function):
         wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
         if partials is not None and training:
             stat, nparts, pitch = partials.v
-            check(L.dcv_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+            check(L.dcv_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
                                              ptr(stats[0]), ptr(stats[1]), ptr(mask), momentum, eps, act, slope, ptr(stat), nparts, pitch,
                                              wsp, wsn, stream_ptr()), "dcv_bn_act_forward_stats")
         else:
             check(L.dcv_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                       ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope, wsp, wsn, stream_ptr()),
+                                       ptr(nbt) if training else None, ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope, wsp, wsn, stream_ptr()),
                   "dcv_bn_act_forward")
         ctx.cfg = (bool(training), act, slope)
         ctx.save_for_backward(x, gamma, beta, stats, mask)
@@ -200,15 +254,18 @@ class _BnAct(Function):
         check(L.dcv_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta),
                                     ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()),
               "dcv_bn_act_backward")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0,
-           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None, partials=None):
-    """y = act(mask * batch_norm(x)); running stats are updated in place when training.
+           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None, partials=None, num_batches_tracked=None):
+    """y = act(mask * batch_norm(x)); running stats (and the int64 `num_batches_tracked` buffer, when given) are
+    updated in place when training.
     `partials`: (buffer, nparts, pitch) left by the producing conv's epilogue (ops.conv(..., bn_stats=[]))."""
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise N.NativeError("bn_act: num_batches_tracked must be an int64 device tensor")
     return _BnAct.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope),
-                        None if out is None else _Out(out), None if partials is None else _Opaque(partials))
+                        None if out is None else _Out(out), None if partials is None else _Opaque(partials), num_batches_tracked)
 
 
 # --------------------------------------------------------------------------- #
@@ -348,12 +405,30 @@ def copy_into(x, dst):
     return _CopyInto.apply(x, _Out(dst))
 
 
+class GradSlot:
+    """Meeting point of the two gradients of a skip tensor (second slice of a ConcatBuffer): the concat's backward
+    runs first (it was recorded later) and leaves its slice here; the data gradient of the tensor's other consumer
+    then accumulates into that slice (`dcv_conv_backward_data(accumulate=1)`) instead of producing a second tensor
+    for autograd to add.  If the order is ever different the slot is simply empty and nothing changes."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+    def take(self, x):
+        g, self.g = self.g, None
+        if g is None or tuple(g.shape) != tuple(x.shape) or g.device != x.device:
+            return None
+        return g
+
+
 class _JoinSlices(Function):
     """cat([a, b], 1) when a and b were WRITTEN INTO adjacent channel slices of `buf` by their
     producers (conv / bn_act with out=): nothing to copy, the result is `buf` itself."""
 
     @staticmethod
-    def forward(ctx, a, b, holder):
+    def forward(ctx, a, b, holder, slot=None):
+        ctx.slot = slot
         buf = holder.t
         ca, cb = a.shape[1], b.shape[1]
         if buf.shape[1] != ca + cb or a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf[:, ca:].data_ptr() \
@@ -364,7 +439,10 @@ class _JoinSlices(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return dy[:, :ctx.ca], dy[:, ctx.ca:], None
+        second = dy[:, ctx.ca:]
+        if ctx.slot is not None:
+            ctx.slot.g = second
+        return dy[:, :ctx.ca], second, None, None
 
 
 class ConcatBuffer:
@@ -373,9 +451,10 @@ class ConcatBuffer:
     def __init__(self, n, ca, cb, spatial, device):
         self.buf = _empty((n, ca + cb) + tuple(spatial), device)
         self.first, self.second = self.buf[:, :ca], self.buf[:, ca:]
+        self.slot = GradSlot() if _SKIP_ACCUMULATE else None
 
     def join(self, a, b):
-        return _JoinSlices.apply(a, b, _Out(self.buf))
+        return _JoinSlices.apply(a, b, _Out(self.buf), self.slot)
 
 
 class _TemporalDiff(Function):

@@ -47,6 +47,7 @@ class Adam:
         L = lib()
         st = stream_ptr()
         ps, gs, ms, vs, ns, keep = [], [], [], [], [], []
+        touched = []
         step = None
         for p in self.params:
             g = p.grad
@@ -60,6 +61,7 @@ class Adam:
             if s is None:
                 s = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)}
             s["step"] += 1
+            touched.append(p)
             if step is None:
                 step = s["step"]
             if s["step"] != step:   # parameters that joined later keep their own bias correction: single-tensor path
@@ -73,6 +75,10 @@ class Adam:
             arr = lambda xs: (C.c_void_p * n)(*xs)
             check(L.dcv_adam_step_multi(n, arr(ps), arr(gs), arr(ms), arr(vs), (C.c_int64 * n)(*ns), self.lr, self.betas[0], self.betas[1],
                                         self.eps, self.weight_decay, step, self.grad_scale, st), "dcv_adam_step_multi")
+        if touched:
+            # the kernels wrote through raw pointers: tell autograd (and the packed-weight caches keyed on it) that
+            # these tensors changed in place
+            torch.autograd.graph.increment_version(touched)
 
 
 class GradBucket:
@@ -162,5 +168,7 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
+        ts = list(module.parameters()) + list(module.buffers())
+        for t in ts:
             dist.broadcast(t.data, src, group=group)
+        torch.autograd.graph.increment_version(ts)   # `.data` writes bypass the version counter

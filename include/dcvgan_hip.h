@@ -76,17 +76,28 @@ int dcv_debug_kernel_info(char* buf, size_t n);
  *   backward_weight: dw  = corr(x, dy)              (deterministic split-K)
  */
 size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which /*0 fwd,1 bwd-data,2 bwd-weight*/);
+/* forward / backward_data read the weights K-major ("packed"); by default they re-pack them into `ws` on every call.
+ * Weights only change at optimiser steps (trainer.py:320-322,357-359) while each layer runs 2-3 times per phase, so a
+ * caller may own the packed copy instead: a buffer of dcv_conv_packed_bytes(g, x, y, which) bytes per (layer, which,
+ * input geometry), passed with ready = 0 the first time after the weights changed (the call packs into it) and
+ * ready = 1 afterwards (the packing launches are skipped).  pack = NULL keeps the default. */
+typedef struct dcv_wpack {
+    float* buf;
+    size_t bytes;
+    int32_t ready;
+} dcv_wpack;
+size_t dcv_conv_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which /*0 fwd,1 bwd-data*/);
 int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w,
-                     float* y, const dcv_dims5* yd, int act, float slope,
+                     float* y, const dcv_dims5* yd, int act, float slope, const dcv_wpack* pack,
                      void* ws, size_t ws_bytes, void* stream);
 /* conv forward that also leaves per-tile BatchNorm partial sums of y (a conv -> BatchNorm pair, generator.py /
  * discriminator.py blocks): stat[part][pitch][2] = {sum, sum of squares}; *nparts = 0 when this geometry's
  * kernel cannot produce them (the caller then runs the plain statistics pass).  No activation, no accumulate. */
 size_t dcv_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
 int dcv_conv_forward_stats(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd,
-                           float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream);
+                           float* stat, size_t stat_bytes, int* nparts, int* pitch, const dcv_wpack* pack, void* ws, size_t ws_bytes, void* stream);
 int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w,
-                           float* dx, const dcv_dims5* dxd, int accumulate,
+                           float* dx, const dcv_dims5* dxd, int accumulate, const dcv_wpack* pack,
                            void* ws, size_t ws_bytes, void* stream);
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd,
                              const float* dy, const dcv_dims5* dyd, float* dw,
@@ -105,7 +116,7 @@ int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_d
 size_t dcv_bn_workspace_bytes(int channels);
 int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd,
                        const float* gamma, const float* beta,
-                       float* running_mean, float* running_var,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked /* may be NULL; += 1 when training */,
                        float* save_mean, float* save_invstd,
                        const float* mask, int training, float momentum, float eps,
                        int act, float slope, void* ws, size_t ws_bytes, void* stream);
@@ -113,7 +124,7 @@ int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_
  * OVERWRITTEN (C floats each). */
 /* dcv_bn_act_forward with the batch statistics taken from dcv_conv_forward_stats' partial sums (training mode) */
 int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* mask,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, const float* mask,
                              float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch,
                              void* ws, size_t ws_bytes, void* stream);
 int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, const dcv_dims5* xd,

@@ -93,6 +93,59 @@ class ReplayRng:
 # --------------------------------------------------------------------------- #
 # tiny helpers
 # --------------------------------------------------------------------------- #
+class KinkTape:
+    """Test instrumentation for the (Leaky)ReLU kinks.  Deep gradients of this network are discontinuous in the
+    pre-activations: one that is within rounding of zero picks the other branch and every upstream gradient moves
+    by ~1e-3.  To compare gradient ARITHMETIC without that lottery, an evaluation can be told which branch each
+    element took elsewhere: with a tape installed (`with KinkTape(masks) as tape:`) the i-th (Leaky)ReLU call
+    computes its forward value from its own input as usual, but differentiates with the i-th recorded pattern
+    (True = identity branch).  `tape.mismatch` collects, per call, the number of elements whose own sign disagrees
+    with the pattern and how far from zero the furthest of them is, relative to the call's rms input."""
+
+    active = None
+
+    def __init__(self, masks):
+        self.masks, self.pos, self.mismatch = masks, 0, []
+
+    def __enter__(self):
+        KinkTape.active = self
+        return self
+
+    def __exit__(self, *a):
+        KinkTape.active = None
+
+    def next(self, x):
+        m = self.masks[self.pos]
+        self.pos += 1
+        assert tuple(m.shape) == tuple(x.shape), (self.pos - 1, tuple(m.shape), tuple(x.shape))
+        own = x.detach() > 0
+        bad = own != m
+        n = int(bad.sum())
+        far = float(x.detach()[bad].abs().max() / x.detach().pow(2).mean().sqrt()) if n else 0.0
+        self.mismatch.append((n, x.numel(), far))
+        return m
+
+
+class _PatternLeaky(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, slope):
+        ctx.save_for_backward(mask)
+        ctx.slope = slope
+        return torch.where(x > 0, x, x * slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * ctx.slope), None, None
+
+
+def _lrelu(x: torch.Tensor, slope: float) -> torch.Tensor:
+    """nn.ReLU (slope 0) / nn.LeakyReLU(slope)."""
+    if KinkTape.active is not None:
+        return _PatternLeaky.apply(x, KinkTape.active.next(x), slope)
+    return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
+
+
 def _bn(st: State, prefix: str, x: torch.Tensor, training: bool) -> torch.Tensor:
     """nn.BatchNorm{2,3}d forward incl. running-stat side effects."""
     rm, rv = st[prefix + ".running_mean"], st[prefix + ".running_var"]
@@ -143,10 +196,10 @@ def ggen_decode(st: State, z: torch.Tensor, training: bool, segmentation=False) 
     """self.main (generator.py:60-80): 5x ConvT2d with BN+ReLU between, Tanh head."""
     h = z.view(z.shape[0], z.shape[1], 1, 1)
     h = F.conv_transpose2d(h, st["main.0.weight"], None, 1, 0)
-    h = F.relu(_bn(st, "main.1", h, training))
+    h = _lrelu(_bn(st, "main.1", h, training), 0.0)
     for conv, bn in ((3, 4), (6, 7), (9, 10)):
         h = F.conv_transpose2d(h, st[f"main.{conv}.weight"], None, 2, 1)
-        h = F.relu(_bn(st, f"main.{bn}", h, training))
+        h = _lrelu(_bn(st, f"main.{bn}", h, training), 0.0)
     h = F.conv_transpose2d(h, st["main.12.weight"], None, 2, 1)
     return torch.softmax(h, 1) if segmentation else torch.tanh(h)
 
@@ -169,11 +222,11 @@ def cgen_forward(st: State, x: torch.Tensor, z: torch.Tensor, rng, training: boo
         idx = torch.argmax(x, 1, keepdim=True)
         x = torch.full_like(x, -1.0).scatter_(1, idx, 1.0)
     # Inconv: conv3x3 + LeakyReLU(default slope 0.01)  (generator.py:173-176)
-    hs = [F.leaky_relu(F.conv2d(x, st["inconv.main.0.weight"], None, 1, 1), 0.01)]
+    hs = [_lrelu(F.conv2d(x, st["inconv.main.0.weight"], None, 1, 1), 0.01)]
     for i in range(6):  # DownBlock (generator.py:203-207)
         h = F.conv2d(hs[-1], st[f"down_blocks.{i}.main.0.weight"], None, 2, 1)
         h = _bn(st, f"down_blocks.{i}.main.1", h, training)
-        hs.append(F.leaky_relu(h, 0.2))
+        hs.append(_lrelu(h, 0.2))
     h = torch.cat([hs[-1], z], 1)  # generator.py:393
     for i in range(6):  # UpBlock (generator.py:238-248)
         if i > 0:
@@ -182,7 +235,7 @@ def cgen_forward(st: State, x: torch.Tensor, z: torch.Tensor, rng, training: boo
         h = _bn(st, f"up_blocks.{i}.main.1", h, training)
         if i < 2 and training:  # Dropout2d(0.5) between BN and ReLU
             h = h * rng.dropout2d_mask(h.shape[0], h.shape[1], 0.5)
-        h = F.relu(h)
+        h = _lrelu(h, 0.0)
     h = torch.cat([h, hs[0]], 1)
     h = F.conv_transpose2d(h, st["outconv.main.0.weight"], None, 1, 1)
     return torch.tanh(h)
@@ -204,12 +257,12 @@ def cgen_forward_videos(st: State, xs: torch.Tensor, dim_z: int, rng, training: 
 # --------------------------------------------------------------------------- #
 def idis_forward(st: State, xg, xc, use_noise: bool, sigma: float, rng, training: bool):
     """ImageDiscriminator.forward (discriminator.py:107-127). Draw order: g, c, main x3."""
-    hg = F.leaky_relu(F.conv2d(_noise(xg, use_noise, sigma, rng), st["conv_g.1.weight"], None, 2, 1), 0.2)
-    hc = F.leaky_relu(F.conv2d(_noise(xc, use_noise, sigma, rng), st["conv_c.1.weight"], None, 2, 1), 0.2)
+    hg = _lrelu(F.conv2d(_noise(xg, use_noise, sigma, rng), st["conv_g.1.weight"], None, 2, 1), 0.2)
+    hc = _lrelu(F.conv2d(_noise(xc, use_noise, sigma, rng), st["conv_c.1.weight"], None, 2, 1), 0.2)
     h = torch.cat([hc, hg], 1)
     for conv, bn in ((1, 2), (5, 6)):
         h = F.conv2d(_noise(h, use_noise, sigma, rng), st[f"main.{conv}.weight"], None, 2, 1)
-        h = F.leaky_relu(_bn(st, f"main.{bn}", h, training), 0.2)
+        h = _lrelu(_bn(st, f"main.{bn}", h, training), 0.2)
     h = F.conv2d(_noise(h, use_noise, sigma, rng), st["main.9.weight"], None, 2, 1)
     return h.squeeze()
 
@@ -220,12 +273,12 @@ _P3 = (0, 1, 1)
 
 def vdis_forward(st: State, xg, xc, use_noise: bool, sigma: float, rng, training: bool):
     """VideoDiscriminator.forward (discriminator.py:211-231); stems carry no Noise."""
-    hg = F.leaky_relu(F.conv3d(xg, st["conv_g.0.weight"], None, _S3, _P3), 0.2)
-    hc = F.leaky_relu(F.conv3d(xc, st["conv_c.0.weight"], None, _S3, _P3), 0.2)
+    hg = _lrelu(F.conv3d(xg, st["conv_g.0.weight"], None, _S3, _P3), 0.2)
+    hc = _lrelu(F.conv3d(xc, st["conv_c.0.weight"], None, _S3, _P3), 0.2)
     h = torch.cat([hc, hg], 1)
     for conv, bn in ((1, 2), (5, 6)):
         h = F.conv3d(_noise(h, use_noise, sigma, rng), st[f"main.{conv}.weight"], None, _S3, _P3)
-        h = F.leaky_relu(_bn(st, f"main.{bn}", h, training), 0.2)
+        h = _lrelu(_bn(st, f"main.{bn}", h, training), 0.2)
     h = F.conv3d(_noise(h, use_noise, sigma, rng), st["main.9.weight"], None, _S3, _P3)
     return h.squeeze()
 
@@ -236,7 +289,7 @@ def gdis_forward(st: State, xg, xc, use_noise: bool, sigma: float, rng, training
     h = xg[:, :, 1:L] - xg[:, :, 0:L - 1]
     for conv, bn in ((1, 2), (5, 6), (9, 10)):
         h = F.conv3d(_noise(h, use_noise, sigma, rng), st[f"main.{conv}.weight"], None, _S3, _P3)
-        h = F.leaky_relu(_bn(st, f"main.{bn}", h, training), 0.2)
+        h = _lrelu(_bn(st, f"main.{bn}", h, training), 0.2)
     h = F.conv3d(_noise(h, use_noise, sigma, rng), st["main.13.weight"], None, _S3, _P3)
     return h.squeeze()
 

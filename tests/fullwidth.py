@@ -1,0 +1,101 @@
+"""Shared by the full-width parity tests: same-seed model construction checked against the fixture's
+init checksums, and one generator-loss forward/backward of the oracle in fp32 or fp64 with the SAME draws."""
+import numpy as np
+import torch
+
+from oracle import dcvgan_oracle as O
+from tests import goldenio as G
+
+MODELS = G.MODELS
+
+
+def same_seed_models(fx, B=None):
+    """The reference builds its five models in a fixed order under one seed (train.py:117-165); the HIP-backed
+    classes consume the init stream identically, so the fixture only stores checksums of the initial tensors."""
+    from dcvgan_amd import trainer
+    cfg = G.cfg_of(fx, B=B, loss=str(fx["meta/loss"]) if "meta/loss" in fx else "adversarial-loss")
+    torch.manual_seed(int(fx["meta/seed_init"]))
+    models = trainer.build_models(cfg, torch.device("cpu"))
+    for n, m in models.items():
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                assert np.allclose(G.summ(v), fx[f"init_sum/{n}/{k}"], rtol=1e-6, atol=1e-6), (n, k)
+    return cfg, models
+
+
+def states_of(models, dtype=torch.float32):
+    st = {}
+    for n, m in models.items():
+        st[n] = {k: (v.detach().cpu().clone().to(dtype) if v.dtype.is_floating_point else v.detach().cpu().clone()) for k, v in m.state_dict().items()}
+        O.require_grad(st[n])
+    return st
+
+
+class Rng64(O.TorchRng):
+    """The fp32 draws of TorchRng, widened: the fp64 graph sees exactly the same random numbers."""
+
+    def normal(self, shape):
+        return super().normal(shape).double()
+
+
+def oracle_gen_pass(cfg, models, seed_run, t, dtype=torch.float32, kinks=None):
+    """ggen -> cgen -> idis/vdis/gdis -> compute_gen_loss -> backward (the G phase of trainer.py:344-356).
+    `kinks`: (Leaky)ReLU branch patterns recorded from another evaluation (oracle.KinkTape) to differentiate with."""
+    if kinks is not None:
+        with O.KinkTape(kinks) as tape:
+            r = oracle_gen_pass(cfg, models, seed_run, t, dtype)
+        assert tape.pos == len(kinks), (tape.pos, len(kinks))
+        r["kink_mismatch"] = tape.mismatch
+        return r
+    st = states_of(models, dtype)
+    torch.manual_seed(seed_run)
+    rng = O.TorchRng() if dtype == torch.float32 else Rng64()
+    B = cfg.batchsize
+    seg = cfg.geometric_info == "segmentation"
+    xg = O.ggen_sample_videos(st["ggen"], B, 16, cfg.dim_z_content, cfg.dim_z_motion, cfg.channel, rng, True, seg)
+    xc = O.cgen_forward_videos(st["cgen"], xg, cfg.dim_z_color, rng, True, seg)
+    yi = O.idis_forward(st["idis"], xg[:, :, t], xc[:, :, t], cfg.use_noise["idis"], cfg.noise_sigma["idis"], rng, True)
+    yv = O.vdis_forward(st["vdis"], xg, xc, cfg.use_noise["vdis"], cfg.noise_sigma["vdis"], rng, True)
+    yg = O.gdis_forward(st["gdis"], xg, xc, cfg.use_noise["gdis"], cfg.noise_sigma["gdis"], rng, True)
+    loss = O.gen_loss(cfg.loss, yi, yv, yg)
+    loss.backward()
+    grads = {}
+    for n in MODELS:
+        for k, p in st[n].items():
+            if p.requires_grad:
+                grads[(n, k)] = None if p.grad is None else p.grad.detach()
+    return dict(xg=xg.detach(), xc=xc.detach(), yi=yi.detach(), yv=yv.detach(), yg=yg.detach(), loss=loss.detach(), grads=grads, log=rng.log, st=st)
+
+
+def to_device(models, dev):
+    for m in models.values():
+        m.to(dev)
+        for mod in m.modules():
+            if hasattr(mod, "device"):
+                mod.device = dev
+    return models
+
+
+def hip_gen_pass(cfg, models, log, t, dev):
+    from dcvgan_amd import layers, trainer
+    from dcvgan_amd.rng import InjectedRng
+    to_device(models, dev)
+    layers.KINK_TAP = kinks = []
+    r = InjectedRng(log)
+    for m in models.values():
+        m._rng = r
+    B = cfg.batchsize
+    xg = models["ggen"].sample_videos(B); xc = models["cgen"].forward_videos(xg)
+    yi = models["idis"](xg[:, :, t], xc[:, :, t]); yv = models["vdis"](xg, xc); yg = models["gdis"](xg, xc)
+    loss = trainer.build_loss(cfg).compute_gen_loss(yi, yv, yg)
+    layers.KINK_TAP = None
+    loss.backward()
+    assert r.pos == len(log)
+    grads = {(n, k): (None if p.grad is None else p.grad.detach().cpu()) for n in MODELS for k, p in models[n].named_parameters()}
+    return dict(xg=xg.detach(), xc=xc.detach(), yi=yi.detach().cpu(), yv=yv.detach().cpu(), yg=yg.detach().cpu(), loss=loss.detach().cpu(), grads=grads,
+                kinks=kinks)
+
+
+def gsub(t):
+    v = t.detach().reshape(-1)
+    return v[::max(1, v.numel() // 256)].cpu().numpy()

@@ -258,11 +258,17 @@ def step_fixture(ref, cfg, name, loss_name, num_gen_update, start_in_eval, B=2, 
 # --------------------------------------------------------------------------- #
 # full-width scalars (real channel counts, values only)
 # --------------------------------------------------------------------------- #
-def fullwidth_fixture(ref, cfg, name, B=2, seed=99):
+def gsub(t: torch.Tensor) -> np.ndarray:
+    """<= ~256 strided elements of a gradient tensor: direction-sensitive, unlike a norm."""
+    v = t.detach().reshape(-1)
+    return v[::max(1, v.numel() // 256)].numpy().copy()
+
+
+def fullwidth_fixture(ref, cfg, name, loss_name="adversarial-loss", B=2, seed=99):
     util, generator, discriminator, loss = ref
     out = {}
     cfg_meta(out, cfg)
-    out["meta/B"] = np.array(B); out["meta/seed_init"] = np.array(seed)
+    out["meta/B"] = np.array(B); out["meta/seed_init"] = np.array(seed); out["meta/loss"] = np.array(loss_name)
     # states are re-derivable: same constructor order under the same seed
     models = build_models(ref, cfg, seed)
     for n, m in models.items():
@@ -276,18 +282,138 @@ def fullwidth_fixture(ref, cfg, name, B=2, seed=99):
     t = 9
     out["meta/t_rand"] = np.array(t)
     yi = idis(xg[:, :, t], xc[:, :, t]); yv = vdis(xg, xc); yg = gdis(xg, xc)
-    L = loss.AdversarialLoss()
+    L = loss.AdversarialLoss() if loss_name == "adversarial-loss" else loss.HingeLoss()
     v = L.compute_gen_loss(yi, yv, yg)
     v.backward()
     out["loss_gen"] = np.array(v.item())
     out["xg_sum"] = summ(xg); out["xc_sum"] = summ(xc)
+    out["xg_stride"] = np.array(xg.stride()); out["xc_stride"] = np.array(xc.stride())
     out["yi"] = yi.detach().numpy().copy(); out["yv"] = yv.detach().numpy().copy(); out["yg"] = yg.detach().numpy().copy()
     for n, m in models.items():
         for k, p in m.named_parameters():
+            if p.grad is None:     # hinge: y_fake_g is unused (loss.py:190-191), gdis gets no gradient
+                out[f"gradnone/{n}/{k}"] = np.array(1)
+                continue
             out[f"gradnorm/{n}/{k}"] = np.array(p.grad.double().norm().item())
+            out[f"gradsub/{n}/{k}"] = gsub(p.grad)
     np.savez(os.path.join(HERE, name), **out)
     print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB")
     return models
+
+
+def step_fullwidth_fixture(ref, cfg, name, loss_name, num_gen_update, lrs, B=2, iters=2, seed=31):
+    """trainer.py:279-363 at the REAL channel widths (initial states re-derivable from the seed, so only
+    scalars and strided samples are stored): losses per iteration, and per tensor the Adam UPDATE
+    theta_after - theta_before of every iteration as {L2 norm, strided sample}."""
+    util, generator, discriminator, loss = ref
+    out = {}
+    cfg_meta(out, cfg)
+    out["meta/B"] = np.array(B); out["meta/iters"] = np.array(iters)
+    out["meta/loss"] = np.array(loss_name); out["meta/num_gen_update"] = np.array(num_gen_update)
+    out["meta/num_dis_update"] = np.array(1); out["meta/start_in_eval"] = np.array(0)
+    out["meta/seed_init"] = np.array(seed)
+    models = build_models(ref, cfg, seed)
+    for n, m in models.items():
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                out[f"init_sum/{n}/{k}"] = summ(v)
+    ggen, cgen, idis, vdis, gdis = (models[k] for k in ("ggen", "cgen", "idis", "vdis", "gdis"))
+    L = loss.AdversarialLoss() if loss_name == "adversarial-loss" else loss.HingeLoss()
+    opt = {n: torch.optim.Adam(m.parameters(), lr=lrs[n], betas=(0.5, 0.999), weight_decay=1e-5) for n, m in models.items()}
+    for n, v in lrs.items():
+        out[f"meta/lr/{n}"] = np.array(v)
+    gdata = torch.Generator().manual_seed(seed + 1)
+    lo, hi = (-0.5, 0.5) if cfg["Cg"] == 2 else (-1.0, 1.0)
+    xc_real = torch.rand(B, 3, 16, 64, 64, generator=gdata) * 2 - 1
+    xg_real = torch.rand(B, cfg["Cg"], 16, 64, 64, generator=gdata) * (hi - lo) + lo
+    out["meta/seed_data"] = np.array(seed + 1)
+    t_rands = [3, 11, 0, 15, 7][:iters]
+    out["meta/t_rands"] = np.array(t_rands)
+    out["meta/seed_run"] = np.array(seed + 2)
+    torch.manual_seed(seed + 2)
+    losses = []
+    for it in range(1, iters + 1):
+        before = {n: {k: p.detach().clone() for k, p in m.named_parameters()} for n, m in models.items()}
+        t = t_rands[it - 1]
+        idis.train(); vdis.train(); gdis.train()
+        idis.zero_grad(); vdis.zero_grad(); gdis.zero_grad()
+        y_real_i = idis(xg_real[:, :, t], xc_real[:, :, t])
+        y_real_v = vdis(xg_real, xc_real)
+        y_real_g = gdis(xg_real, xc_real)
+        xg_fake = ggen.sample_videos(B)
+        xc_fake = cgen.forward_videos(xg_fake)
+        y_fake_i = idis(xg_fake[:, :, t], xc_fake[:, :, t])
+        y_fake_v = vdis(xg_fake, xc_fake)
+        y_fake_g = gdis(xg_fake, xc_fake)
+        loss_idis = L.compute_dis_loss(y_real_i, y_fake_i)
+        loss_vdis = L.compute_dis_loss(y_real_v, y_fake_v)
+        loss_gdis = L.compute_dis_loss(y_real_g, y_fake_g)
+        loss_dis = loss_idis + loss_vdis + loss_gdis
+        if it % num_gen_update == 0:
+            loss_dis.backward()
+            opt["idis"].step(); opt["vdis"].step(); opt["gdis"].step()
+        ggen.train(); cgen.train()
+        ggen.zero_grad(); cgen.zero_grad()
+        xg_fake = ggen.sample_videos(B)
+        xc_fake = cgen.forward_videos(xg_fake)
+        y_fake_i = idis(xg_fake[:, :, t], xc_fake[:, :, t])
+        y_fake_v = vdis(xg_fake, xc_fake)
+        y_fake_g = gdis(xg_fake, xc_fake)
+        loss_gen = L.compute_gen_loss(y_fake_i, y_fake_v, y_fake_g)
+        loss_gen.backward()
+        opt["ggen"].step(); opt["cgen"].step(); opt["ggen"].step()
+        losses.append([loss_idis.item(), loss_vdis.item(), loss_gdis.item(), loss_gen.item()])
+        for n, m in models.items():
+            for k, p in m.named_parameters():
+                d = p.detach() - before[n][k]
+                out[f"delta{it}/{n}/{k}/norm"] = np.array(d.double().norm().item())
+                out[f"delta{it}/{n}/{k}/sub"] = gsub(d)
+            for k, v in m.state_dict().items():
+                if "running" in k:
+                    out[f"after{it}/{n}/{k}"] = summ(v)
+    out["losses"] = np.array(losses)
+    np.savez(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB", losses)
+
+
+def stress_d_fixture(ref, name="stress_d_32x128x128.npz", seed=555):
+    """The 32 x 128 x 128 discriminator stress shape (BASELINE configs[4]): vdis / gdis are
+    size-agnostic (discriminator.py:181-206,288-305), so the reference classes run it directly.  B = 1 (so
+    `.squeeze()` also drops the batch dimension), flow channels, isogd-flow's noise settings."""
+    util, generator, discriminator, loss = ref
+    out = {}
+    torch.manual_seed(seed)
+    vdis = discriminator.VideoDiscriminator(2, 3, True, 0.2, 64)
+    gdis = discriminator.GradientDiscriminator(2, 3, False, 0.2, 32)
+    for m in (vdis, gdis):
+        m.apply(util.init_weights)
+        m.train()
+    out["meta/seed_init"] = np.array(seed)
+    for n, m in (("vdis", vdis), ("gdis", gdis)):
+        for k, v in m.state_dict().items():
+            if v.dtype.is_floating_point:
+                out[f"init_sum/{n}/{k}"] = summ(v)
+    g = torch.Generator().manual_seed(seed + 1)
+    out["meta/seed_inputs"] = np.array(seed + 1)
+    xg = (torch.rand(1, 32, 2, 128, 128, generator=g) - 0.5).permute(0, 2, 1, 3, 4).requires_grad_(True)   # the generators' memory order
+    xc = (torch.rand(1, 32, 3, 128, 128, generator=g) * 2 - 1).permute(0, 2, 1, 3, 4).requires_grad_(True)
+    torch.manual_seed(seed + 2)
+    out["meta/seed_fwd"] = np.array(seed + 2)
+    yv = vdis(xg, xc); yg = gdis(xg, xc)
+    out["yv"] = yv.detach().numpy().copy(); out["yg"] = yg.detach().numpy().copy()
+    tot = (yv * torch.linspace(1, -1, yv.numel()).view(yv.shape)).sum() + (yg * torch.linspace(-0.5, 1.5, yg.numel()).view(yg.shape)).sum()
+    tot.backward()
+    out["grad_xg_sub"] = sub(xg.grad, 101); out["grad_xg_sum"] = summ(xg.grad)
+    out["grad_xc_sub"] = sub(xc.grad, 101); out["grad_xc_sum"] = summ(xc.grad)
+    for n, m in (("vdis", vdis), ("gdis", gdis)):
+        for k, p in m.named_parameters():
+            out[f"gradnorm/{n}/{k}"] = np.array(p.grad.double().norm().item())
+            out[f"gradsub/{n}/{k}"] = gsub(p.grad)
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                out[f"after/{n}/{k}"] = v.detach().numpy().copy()
+    np.savez(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(v.nbytes for v in out.values()) / 1e6, "MB", tuple(yv.shape), tuple(yg.shape))
 
 
 def sampling_fixture(ref, cfg, name, seed=4321):
@@ -390,6 +516,16 @@ if __name__ == "__main__":
     full = dict(geo="depth", Cg=1, dzc=40, dzm=10, dzcol=10, ngf_g=64, ngf_c=64, ndf_i=64, ndf_v=64, ndf_g=32,
                 noise_i=(True, 0.1), noise_v=(True, 0.1), noise_g=(False, 0.2))
     fullwidth_fixture(ref, full, "fullwidth_isogd_depth.npz")
+    # config/surreal-depth1.yml:5,27,30,47-76 (ggen ngf 96, no Noise, hinge; the yml has no gdis block: isogd's ndf 32 is injected)
+    full_surreal = dict(full, ngf_g=96, noise_i=(False, 0.2), noise_v=(False, 0.2), noise_g=(False, 0.2))
+    # config/isogd-flow.yml:5,9-10,16-18,27 (two flow channels, noise sigma 0.2, hinge)
+    full_flow = dict(full, geo="optical-flow", Cg=2, noise_i=(True, 0.2), noise_v=(True, 0.2), noise_g=(False, 0.2))
+    fullwidth_fixture(ref, full_surreal, "fullwidth_surreal_depth1.npz", "hinge-loss", seed=199)
+    fullwidth_fixture(ref, full_flow, "fullwidth_isogd_flow.npz", "hinge-loss", seed=299)
+    lr2 = dict(ggen=2e-4, cgen=2e-4, idis=2e-4, vdis=2e-4, gdis=2e-4)
+    step_fullwidth_fixture(ref, full_surreal, "step_fullwidth_surreal_depth1.npz", "hinge-loss", 2, lr2)
+    step_fullwidth_fixture(ref, full_flow, "step_fullwidth_isogd_flow.npz", "hinge-loss", 1, lr2, seed=41)
+    stress_d_fixture(ref)
     sampling_fixture(ref, dict(small_depth, ngf_g=4, ngf_c=4), "sampling_depth_w4.npz")
     interchange_fixture(ref)
     small_segm = dict(geo="segmentation", Cg=25, dzc=4, dzm=2, dzcol=2, ngf_g=4, ngf_c=4, ndf_i=4, ndf_v=4, ndf_g=4,

@@ -51,7 +51,11 @@ def test_argument_validation_needs_no_gpu(lib):
     assert b"extent" in lib.dcv_last_error()
     for which in (0, 1, 2):
         assert lib.dcv_conv_workspace_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), which) > 0
-    assert lib.dcv_conv_forward(ctypes.byref(g), None, ctypes.byref(x), None, None, ctypes.byref(y_ok), 0, 0.0, None, 0, None) == -1
+    assert lib.dcv_conv_forward(ctypes.byref(g), None, ctypes.byref(x), None, None, ctypes.byref(y_ok), 0, 0.0, None, None, 0, None) == -1
+    # packed-weight buffer sizes (dcv_wpack) are host arithmetic too: K = 3 channels x 16 taps = 48 rows x 32 padded output channels
+    assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 0) == 48 * 32 * 4
+    assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 1) > 0
+    assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 2) == 0
 
 
 def test_product_path_has_no_cpu_fallback(lib):

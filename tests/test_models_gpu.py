@@ -189,126 +189,57 @@ def test_training_step(dev, fixture, elide):
     lo, hi = (-0.5, 0.5) if cfg.channel == 2 else (-1.0, 1.0)
     xc_real = torch.rand(B, 3, 16, 64, 64, generator=gd) * 2 - 1
     xg_real = torch.rand(B, cfg.channel, 16, 64, 64, generator=gd) * (hi - lo) + lo
-    # oracle run (records every draw)
+    # oracle run (records every draw, keeps the parameters after every iteration)
     torch.manual_seed(int(fx["meta/seed_run"]))
     so = O.StepOracle(cfg, G.states(fx))
     iters = int(fx["meta/iters"])
-    oracle_losses = [so.step(xc_real, xg_real, int(fx["meta/t_rands"][i])) for i in range(iters)]
+    snap = lambda: {n: {k: v.detach().clone() for k, v in so.st[n].items()} for n in G.MODELS}
+    oracle_states = [snap()]
+    for i in range(iters):
+        so.step(xc_real, xg_real, int(fx["meta/t_rands"][i]))
+        oracle_states.append(snap())
     # HIP run with the same draws
     models = hip_models(fx, cfg, dev)
     r = share_rng(models, so.rng.log)
     runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True,
                                 elide_dead_backward=elide)
     xc_d, xg_d = xc_real.to(dev), xg_real.to(dev)
+    flipped_total = checked_total = 0
     for it in range(1, iters + 1):
+        before = {n: {k: v.detach().clone() for k, v in models[n].state_dict().items()} for n in G.MODELS}
         got = runner.step(xc_d, xg_d, int(fx["meta/t_rands"][it - 1]))
         got = [got["loss_idis"], got["loss_vdis"], got["loss_gdis"], got["loss_gen"]]
         assert np.allclose(got, fx["losses"][it - 1], rtol=TOL, atol=1e-5), (it, got, fx["losses"][it - 1])
+        d_updated = it % cfg.num_gen_update == 0
         for n in G.MODELS:
+            lr = float(fx[f"meta/lr/{n}"]) * (2 if n == "ggen" else 1)      # ggen is stepped twice per iteration (trainer.py:357-359)
             for k, v in models[n].state_dict().items():
                 ref = fx[f"after{it}/{n}/{k}"]
-                v = v.detach().float().reshape(-1).double().cpu()
-                chk = np.concatenate([[v.abs().sum().item(), v.sum().item()], v[:8].numpy()])
-                # The loss trajectory (above) is the tight check.  Parameters: Adam's first steps move
-                # every element by ~lr * sign(g), so ONE ReLU kink flip (a pre-activation within fp32
-                # rounding of 0 — observed: +1.2e-6 on CPU vs <= 0 on HIP in cgen.up_blocks.5) can flip
-                # the update of an element whose gradient is ~0.  Bound: |delta| <= 2.1 * lr per Adam step
-                # (ggen is stepped twice per iteration, trainer.py:357-359).
-                lr = float(fx[f"meta/lr/{n}"])
-                steps = it * (2 if n == "ggen" else 1)
-                # sum|theta|: exact to 1e-3 plus at most a quarter of the elements having moved the other way
-                assert np.allclose(chk[:1], ref[:1], rtol=1e-3, atol=0.25 * v.numel() * 2 * lr * steps), (it, n, k, chk, ref)
-                assert np.allclose(chk[2:], ref[2:len(chk)], rtol=2e-3, atol=2.1 * lr * steps), (it, n, k, chk, ref)
+                vd = v.detach().float().reshape(-1).double().cpu()
+                # the reference's own checksum sum|theta| (BatchNorm biases start at 0, so theirs is a sum of Adam moves:
+                # a tenth of the elements may have moved the other way)
+                assert np.allclose(vd.abs().sum().item(), ref[0], rtol=1e-3, atol=0.1 * vd.numel() * lr), (it, n, k)
+                if not v.dtype.is_floating_point or "running" in k:
+                    continue
+                # The UPDATE theta_after - theta_before against the oracle's (pinned to the reference's checksums by
+                # tests/test_oracle_golden.py::test_step).  Adam's first steps move an element by ~lr * sign(g), so an
+                # element whose gradient is ~0 relative to the gradient's error (ReLU kink flips upstream, see
+                # DESIGN §3) can land on the other side: such elements are COUNTED (|difference| > lr / 2) and may be
+                # at most 5 % of a tensor (two elements for tiny tensors) and 1 % over all tensors; all others must agree to 0.25 relative L2 (at these
+                # tiny widths one kink flip moves the deepest gradients — the GRU's — by several per cent; the
+                # arithmetic of the update itself is pinned to 1e-6 by tests/test_adam_gpu.py).
+                d_hip = vd - before[n][k].reshape(-1).double().cpu()
+                d_ref = (oracle_states[it][n][k] - oracle_states[it - 1][n][k]).reshape(-1).double()
+                if n.endswith("dis") and not d_updated:
+                    assert float(d_ref.abs().max()) == 0.0 and float(d_hip.abs().max()) == 0.0, (it, n, k)   # update gated off
+                    continue
+                assert float(d_ref.norm()) > 0.0
+                flipped = (d_hip - d_ref).abs() > 0.5 * lr
+                nf = int(flipped.sum())
+                assert nf <= max(2, int(0.05 * d_ref.numel())), (it, n, k, nf, d_ref.numel())
+                keep = ~flipped
+                err = float((d_hip - d_ref)[keep].norm() / d_ref[keep].norm().clamp_min(1e-30))
+                assert err <= 0.25, (it, n, k, err)
+                flipped_total += nf; checked_total += d_ref.numel()
     assert r.pos == len(so.rng.log)
-
-
-def test_fullwidth_scalars(dev):
-    """Real isogd-depth channel widths (64/64/64/64/32), B=2: D logits, generator loss and every
-    parameter-gradient norm against the reference's numbers."""
-    from dcvgan_amd import trainer
-    from dcvgan_amd.configs import CONFIGS
-    fx = G.load("fullwidth_isogd_depth.npz")
-    cfg = CONFIGS["isogd-depth"].scaled(batchsize=2)
-    torch.manual_seed(int(fx["meta/seed_init"]))
-    models = trainer.build_models(cfg, torch.device("cpu"))  # same constructor order => same init stream
-    for n, m in models.items():
-        for k, v in m.state_dict().items():
-            if v.dtype.is_floating_point:
-                assert np.allclose(G.summ(v), fx[f"init_sum/{n}/{k}"], rtol=1e-6, atol=1e-6), (n, k)
-    st = {n: {k: v.detach().clone() for k, v in m.state_dict().items()} for n, m in models.items()}
-    torch.manual_seed(int(fx["meta/seed_run"]))
-    rng = O.TorchRng(); t = int(fx["meta/t_rand"])
-    with torch.no_grad():
-        xg_o = O.ggen_sample_videos(st["ggen"], 2, 16, 40, 10, 1, rng, True)
-        xc_o = O.cgen_forward_videos(st["cgen"], xg_o, 10, rng, True)
-        O.idis_forward(st["idis"], xg_o[:, :, t], xc_o[:, :, t], True, 0.1, rng, True)
-        O.vdis_forward(st["vdis"], xg_o, xc_o, True, 0.1, rng, True)
-        O.gdis_forward(st["gdis"], xg_o, xc_o, False, 0.2, rng, True)
-    for m in models.values():
-        m.to(dev)
-        for mod in m.modules():
-            if hasattr(mod, "device"):
-                mod.device = dev
-    share_rng(models, rng.log)
-    xg = models["ggen"].sample_videos(2); xc = models["cgen"].forward_videos(xg)
-    yi = models["idis"](xg[:, :, t], xc[:, :, t]); yv = models["vdis"](xg, xc); yg = models["gdis"](xg, xc)
-    assert np.allclose(G.summ(xg), fx["xg_sum"], rtol=TOL) and np.allclose(G.summ(xc), fx["xc_sum"], rtol=TOL)
-    for y, k in ((yi, "yi"), (yv, "yv"), (yg, "yg")):
-        assert G.relerr(y.detach().cpu().numpy(), fx[k]) < TOL, k
-    v = trainer.build_loss(cfg).compute_gen_loss(yi, yv, yg)
-    assert abs(v.item() - float(fx["loss_gen"])) < TOL * abs(float(fx["loss_gen"]))
-    v.backward()
-    for n, m in models.items():
-        for k, p in m.named_parameters():
-            ref = float(fx[f"gradnorm/{n}/{k}"])
-            # Gradients ~50 layers deep at B=2 over ~1e8 (Leaky)ReLU pre-activations are ill-conditioned:
-            # tools/dbg6.py measures the reference's own fp32 CPU gradients 1.2e-3..2.3e-3 (relative) away
-            # from an fp64 evaluation of the same graph, and the HIP ones 4e-3..6e-3 (kink flips; the
-            # MFMA's k-ordered fp32 chain at K = 8192 rounds more than oneDNN's blocked sums).  So the
-            # generator-side norms are held to 1e-2, the discriminator-side ones (shallow) to 2e-3.
-            tol = 1e-2 if n in ("ggen", "cgen") else 2e-3
-            assert abs(p.grad.double().norm().item() - ref) < tol * max(ref, 1e-12), (n, k, p.grad.double().norm().item(), ref)
-
-
-def test_fullwidth_b16_against_the_oracle(dev):
-    """Real isogd-depth widths at B=16: large enough that every big-problem kernel variant is taken (row-reuse
-    thin kernels, patch staging, depth-step, fused BN statistics, both LDS-DMA weight-gradient tiles — the B=2
-    fixture above runs their small-problem / split-K alternatives).  Reference values: the pinned oracle on the
-    CPU, same weights and draws."""
-    from dcvgan_amd import trainer
-    from dcvgan_amd.configs import CONFIGS
-    B = 16
-    cfg = CONFIGS["isogd-depth"].scaled(batchsize=B)
-    torch.manual_seed(123)
-    models = trainer.build_models(cfg, torch.device("cpu"))
-    st = {n: {k: v.detach().clone() for k, v in m.state_dict().items()} for n, m in models.items()}
-    for n in st:
-        O.require_grad(st[n])
-    torch.manual_seed(321)
-    rng = O.TorchRng(); t = 7
-    xg_o = O.ggen_sample_videos(st["ggen"], B, 16, 40, 10, 1, rng, True)
-    xc_o = O.cgen_forward_videos(st["cgen"], xg_o, 10, rng, True)
-    yi_o = O.idis_forward(st["idis"], xg_o[:, :, t], xc_o[:, :, t], True, 0.1, rng, True)
-    yv_o = O.vdis_forward(st["vdis"], xg_o, xc_o, True, 0.1, rng, True)
-    yg_o = O.gdis_forward(st["gdis"], xg_o, xc_o, False, 0.2, rng, True)
-    loss_o = O.gen_loss("adversarial-loss", yi_o, yv_o, yg_o)
-    loss_o.backward()
-    for m in models.values():
-        m.to(dev)
-        for mod in m.modules():
-            if hasattr(mod, "device"):
-                mod.device = dev
-    share_rng(models, rng.log)
-    xg = models["ggen"].sample_videos(B); xc = models["cgen"].forward_videos(xg)
-    yi = models["idis"](xg[:, :, t], xc[:, :, t]); yv = models["vdis"](xg, xc); yg = models["gdis"](xg, xc)
-    assert G.relerr(xg.detach().cpu().numpy(), xg_o.detach().numpy()) < TOL and G.relerr(xc.detach().cpu().numpy(), xc_o.detach().numpy()) < TOL
-    for y, yo, k in ((yi, yi_o, "yi"), (yv, yv_o, "yv"), (yg, yg_o, "yg")):
-        assert G.relerr(y.detach().cpu().numpy(), yo.detach().numpy()) < TOL, k
-    v = trainer.build_loss(cfg).compute_gen_loss(yi, yv, yg)
-    assert abs(v.item() - loss_o.item()) < TOL * abs(loss_o.item())
-    v.backward()
-    for n, m in models.items():
-        for k, p in m.named_parameters():
-            ref = st[n][k].grad.double().norm().item()
-            tol = 1e-2 if n in ("ggen", "cgen") else 2e-3   # conditioning: see test_fullwidth_scalars
-            assert abs(p.grad.double().norm().item() - ref) < tol * max(ref, 1e-12), (n, k, p.grad.double().norm().item(), ref)
+    assert flipped_total <= 0.01 * checked_total, (flipped_total, checked_total)

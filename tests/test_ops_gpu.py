@@ -98,6 +98,40 @@ def test_conv_fwd_bwd(dev, case, strided):
     assert rel(gw, gw_ref) < TOL
 
 
+@pytest.mark.parametrize("case", [c for c in CONVS if c[0] in ("conv2d_4s2p1", "conv2d_4s2p1_wide", "conv2d_4s2p1_32_oc40", "conv2d_4s2p1_32_oc130",
+                                                                "conv2d_4s2p1_8_oc72", "conv2d_3s1p1", "conv3d_4s122_16_oc70", "convT2d_4s2p1_16_oc36")],
+                         ids=lambda c: c[0])
+def test_conv_backward_data_accumulates_into_a_slice(dev, case):
+    """dcv_conv_backward_data(accumulate = 1): dx += conv^T(dy, w) where dx is a channel slice of a wider buffer that
+    already holds another gradient — how the data gradients of the U-Net's down blocks join the concat's gradient
+    slices (ops.GradSlot) without a separate add."""
+    import ctypes as C
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    name, tr, nd, cin, cout, k, s, p, sp, n = case
+    g = torch.Generator().manual_seed(hash(name) % 1000 + 7)
+    s_t = (s,) * nd if isinstance(s, int) else s
+    p_t = (p,) * nd if isinstance(p, int) else p
+    w = torch.randn(((cin, cout) if tr else (cout, cin)) + (k,) * nd, generator=g) * 0.2
+    x = torch.randn((n, cin) + sp, generator=g, requires_grad=True)
+    fn = {(False, 2): F.conv2d, (False, 3): F.conv3d, (True, 2): F.conv_transpose2d}[(tr, nd)]
+    y = fn(x, w, None, s_t, p_t)
+    dy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad((y * dy).sum(), [x])
+    wide = torch.randn((n, cin + 5) + sp, generator=g)            # the buffer: 5 foreign channels, then the slice
+    want = wide.clone(); want[:, 5:] += gx
+    wide_d, dy_d, w_d = wide.to(dev), dy.to(dev), w.to(dev)
+    dx = wide_d[:, 5:]
+    geom = ops.conv_geom(w_d, s_t, p_t, tr)
+    dxd, dyd = dims5(dx), dims5(dy_d)
+    L = N.lib()
+    need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(dxd), C.byref(dyd), 1)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    N.check(L.dcv_conv_backward_data(C.byref(geom), ptr(dy_d), C.byref(dyd), ptr(w_d), ptr(dx), C.byref(dxd), 1, None, ptr(ws), need, stream_ptr()), "accumulate")
+    assert rel(wide_d, want) < 1e-5
+    assert torch.equal(wide_d[:, :5].cpu(), wide[:, :5])          # the neighbouring channels are untouched
+
+
 def test_conv_fused_act(dev):
     from dcvgan_amd import ops
     g = torch.Generator().manual_seed(3)

@@ -81,10 +81,10 @@ for (name, tr, cin, cout, k, s, p, xs, nf, nd, nw) in L:
     dx = torch.empty_like(x); dw = torch.empty_like(w)
     def fwd():
         need = Lb.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0); wsp, wsn = ops._ws("conv", need, dev)
-        N.check(Lb.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, 0.0, wsp, wsn, stream_ptr()), "f")
+        N.check(Lb.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, 0.0, None, wsp, wsn, stream_ptr()), "f")
     def dgrad():
         need = Lb.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 1); wsp, wsn = ops._ws("conv", need, dev)
-        N.check(Lb.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(yd), ptr(w), ptr(dx), C.byref(xd), 0, wsp, wsn, stream_ptr()), "d")
+        N.check(Lb.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(yd), ptr(w), ptr(dx), C.byref(xd), 0, None, wsp, wsn, stream_ptr()), "d")
     def wgrad():
         need = Lb.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 2); wsp, wsn = ops._ws("conv", need, dev)
         N.check(Lb.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(yd), ptr(dw), wsp, wsn, stream_ptr()), "w")

@@ -14,17 +14,17 @@ L.dcv_conv_workspace_bytes.restype = C.c_size_t
 need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0)
 ws = torch.empty(need, dtype=torch.uint8, device=dev)
 for _ in range(2):
-    rc = L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
+    rc = L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), None, C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
     assert rc == 0
 torch.cuda.synchronize()
 def run(lib_):
     lib_.dcv_conv_workspace_bytes.restype = C.c_size_t
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
-        lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
+        lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), None, C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
     e0.record()
     for _ in range(5):
-        lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
+        lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), None, C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / 5
 Lp = C.CDLL("dcvgan_amd/libdcvgan_hip.so")

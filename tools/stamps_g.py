@@ -20,10 +20,10 @@ for name in sys.argv[1:] or ["up5"]:
     def run(lib_, n=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(2):
-            assert lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr()) == 0
+            assert lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), None, C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr()) == 0
         e0.record()
         for _ in range(n):
-            lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
+            lib_.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, C.c_float(0.0), None, C.c_void_p(ws.data_ptr()), C.c_size_t(need), stream_ptr())
         e1.record(); e1.synchronize()
         return e0.elapsed_time(e1) / n
     for rep in range(2):
