@@ -1,18 +1,25 @@
 #!/usr/bin/env python3
-"""videos/s of the DCVGAN G+D training step (config/isogd-depth.yml) on MI355X.
+"""videos/s of the DCVGAN G+D training iteration on MI355X (default: config/isogd-depth.yml, B = 70 per GPU, fp32).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config isogd-depth|surreal-depth1|isogd-flow]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One step = the reference trainer's iteration (trainer.py:279-363): D phase (3 D's on real and
-fake batches, backward, 3 Adam steps) + G phase (fresh fakes, backward, ggen/cgen/ggen Adam
-steps), fp32, synthetic U(-1,1) clips of shape (B,3,16,64,64)+(B,1,16,64,64) resident in HBM,
-per-GPU batch 70.  N > 1 is weak-scaling data parallel: every rank runs the step on its own
-batch and RNG stream; gradients are all-reduced (RCCL) inside the optimiser wrapper.
+One step = the reference trainer's iteration (trainer.py:279-363): D phase (3 D's on the real and the fake batch,
+backward, 3 Adam steps — gated by num_gen_update) + G phase (fresh fakes, backward, ggen / cgen / ggen Adam steps),
+fp32, synthetic clips of shape (B,3,16,64,64) + (B,Cg,16,64,64) resident in HBM.  N > 1 is weak-scaling data parallel:
+every rank runs the step on its own batch and RNG stream; the gradients of a phase are all-reduced (RCCL) as ONE
+bucket inside the optimiser wrapper (dcvgan_amd/optim.py).
 
-Rank 0 prints ONE JSON line.  `roofline` = conv/convT/GRU FLOPs of the as-written step
- x videos/s against the dense fp32 MFMA peak, plus the dominant kernel
-timed alone with HIP events; `cpu_baseline` = the CPU oracle's step on this host's cores.
+Rank 0 prints ONE JSON line.
+  roofline      bound "mfma".  achieved / frac: the dominant kernel (cgen.up_blocks.5 forward, the step's largest single
+                GEMM: 2 * M * OC * K FLOP per launch) timed alone with HIP events on the stream it is launched on,
+                against the dense fp32 MFMA peak; `step` holds the whole iteration priced the same way
+                (conv / convT / GRU FLOPs of the as-written schedule x videos/s), `hbm` the iteration's algorithmic
+                bytes per second against 8 TB/s.  `traffic` (HBM bytes per launch of the dominant kernel from
+                rocprofv3 PMC passes) cannot be collected from inside the process: it is read from the committed
+                profile of the SAME batch size, else null.
+  cpu_baseline  the CPU oracle's step (pure-torch restatement of the reference trainer, pinned to the reference by
+                tests/golden) on this host's cores — rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -25,7 +32,8 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_HBM_GBPS = 8000.0          # same guide, HBM3E
 
 
 def parse():
@@ -40,34 +48,47 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the DP path on one GPU)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--no-minimal", action="store_true", help="skip the secondary run with the dead D-phase generator backward elided")
+    ap.add_argument("--minimal", action="store_true", help="also time the schedule with the dead D-phase generator backward elided (secondary line)")
+    ap.add_argument("--no-minimal", action="store_true", help="(default; kept for older command lines)")
     return ap.parse_args()
 
 
 def dominant_kernel_probe(models, cfg, dev):
-    """Time the step's largest single launch family alone: cgen.up_blocks[5] forward
-    (ConvTranspose2d 128->64, 4x4 s2 p1 on (F,128,32,32); 4.29 GFLOP/video)
-    = 4 stride-parity launches of gather_gemm_kernel<2,2,1,4> + 4 weight packs."""
-    from dcvgan_amd import layers, ops
+    """The step's largest single launch: cgen.up_blocks[5] forward — ConvTranspose2d 128 -> 64, 4x4 s2 p1 on (F,128,32,32),
+    4.29 GFLOP/video: the 4 stride-parity classes run as ONE gather-GEMM launch.  Timed with HIP
+    events recorded on the stream the library launches on (the current stream)."""
+    from dcvgan_amd import layers, native, ops
     conv = models["cgen"].up_blocks[5].main[0]
     F_ = cfg.batchsize * cfg.video_length
     x = torch.randn(F_, conv.in_channels, 32, 32, device=dev)
     g = layers.geom_of(conv)
     with torch.no_grad():
-        for _ in range(2):
-            ops.conv(x, conv.weight, g)
+        for _ in range(3):
+            ops.conv(x, conv.weight, g)     # the first call also packs the weights (cached afterwards, as in the step)
+        name = native.lib().dcv_debug_last_kernel().decode()
         s = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 5
+        reps = 10
         e0.record(s)
         for _ in range(reps):
             ops.conv(x, conv.weight, g)
         e1.record(s)
         e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * F_ * 64 * 64 * conv.out_channels * conv.in_channels * 4  # 2x2 taps per output
-    return {"name": "gather_gemm_kernel<2,2,1,4> x4 (cgen.up_blocks.5 fwd)", "ms": ms, "gflop": flops / 1e9,
-            "achieved": flops / ms / 1e9, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS}
+    flops = 2.0 * F_ * 64 * 64 * conv.out_channels * conv.in_channels * 4  # 2x2 taps per output position
+    return {"layer": "cgen.up_blocks.5 forward", "kernel": name, "ms": ms, "gflop_per_launch": flops / 1e9, "tflops": flops / ms / 1e9}
+
+
+def committed_traffic(batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_layer.sh; FETCH_SIZE
+    doubled for the 16-byte-per-lane operand streams as the MI355X guide prescribes) — only when it was taken at this batch."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")))
+        if int(t.get("batch", -1)) == int(batch):
+            return {"bytes_per_launch": t["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "source": "profiles/r02_dominant_kernel_pmc.json"}
+    except Exception:
+        pass
+    return None
 
 
 def host_threads():
@@ -80,6 +101,16 @@ def host_threads():
     except Exception:
         pass
     return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg, batch, steps):
@@ -99,9 +130,9 @@ def cpu_baseline(cfg, batch, steps):
     for i in range(steps):
         so.step(xc, xg, i)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": batch / dt, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of the CPU oracle (pure-torch restatement of trainer.py:279-363), batch {batch}, "
-                      f"{cfg.name} widths, fp32, {dt:.2f} s/step"}
+    return {"value": batch / dt, "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model(),
+            "sample": f"{steps} steps of the CPU oracle (pure-torch restatement of trainer.py:279-363, pinned to the reference by tests/golden), "
+                      f"batch {batch}, {cfg.name} widths, fp32, {dt:.2f} s/step"}
 
 
 def main():
@@ -124,7 +155,7 @@ def main():
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE {world}"
 
     from dcvgan_amd import native, optim, trainer
-    from dcvgan_amd.configs import CONFIGS, FLOPS_PER_VIDEO_STEP
+    from dcvgan_amd.configs import ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION, CONFIGS, flops_per_video_iteration
     native.lib()
     cfg = CONFIGS[a.config]
     if a.batch:
@@ -152,68 +183,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(run, steps, first):
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = run.step(xc, xg, (first + i) % cfg.video_length)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, out
+
     n0 = native.launch_count()
     for i in range(a.warmup):
         runner.step(xc, xg, i % cfg.video_length)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = runner.step(xc, xg, (a.warmup + i) % cfg.video_length)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt, out = timed(runner, a.steps, a.warmup)
     launches = native.launch_count() - n0
     losses = {k: float(v) for k, v in out.items()}
-
-    # secondary, clearly labelled: same parameters/updates, dead D-phase generator backward elided
-    minimal = None
-    if not a.no_minimal:
-        runner2 = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=False, elide_dead_backward=True)
-        runner2.step(xc, xg, 0)
-        sync()
-        t1 = time.perf_counter()
-        for i in range(a.steps):
-            runner2.step(xc, xg, i % cfg.video_length)
-        sync()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = t.item()
-        f_min = FLOPS_PER_VIDEO_STEP[a.config][1]
-        minimal = {"note": "NOT the headline: D-phase fakes built without a tape (StepRunner(elide_dead_backward=True)); identical "
-                           "parameter updates, FLOPs = BASELINE.md 'minimal' column",
-                   "value": B * world / (dt2 / a.steps), "unit": "videos/s", "ms_per_step": dt2 / a.steps * 1e3,
-                   "flops_per_video_step": f_min, "frac": f_min * (B / (dt2 / a.steps)) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     assert all(x == x and abs(x) < 1e4 for x in losses.values()), losses
 
+    # secondary, clearly labelled and off by default: identical parameter updates, the dead D-phase generator backward elided
+    minimal = None
+    if a.minimal:
+        runner2 = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=False, elide_dead_backward=True)
+        runner2.iteration = runner.iteration
+        runner2.step(xc, xg, 0)
+        dt2, _ = timed(runner2, a.steps, 1)
+        f_min = flops_per_video_iteration(cfg, True)
+        minimal = {"note": "NOT the headline: D-phase fakes built without a tape (StepRunner(elide_dead_backward=True)); identical parameter "
+                           "updates, FLOPs = BASELINE.md 'minimal' column",
+                   "value": B * world / (dt2 / a.steps), "unit": "videos/s", "ms_per_step": dt2 / a.steps * 1e3,
+                   "flops_per_video_step": f_min, "frac": f_min * (B / (dt2 / a.steps)) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+
     if rank == 0:
-        ms = dt / a.steps * 1e3
-        vps = B * world / (dt / a.steps)
-        f_step = FLOPS_PER_VIDEO_STEP[a.config][0]
-        tfl = f_step * (B / (dt / a.steps)) / 1e12  # per GPU
+        per_step = dt / a.steps
+        vps = B * world / per_step
+        f_step = flops_per_video_iteration(cfg)
+        step_tflops = f_step * (B / per_step) / 1e12        # per GPU
         probe = dominant_kernel_probe(models, cfg, dev)
-        traffic = None
-        try:  # HBM bytes per step from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE are in KB)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            kb = sum(v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in pm.values())
-            traffic = {"hbm_gb_per_step": kb * 1024 / 2 / 1e9, "algorithmic_gb_per_step": 1.06 * B, "source": "profiles/r01_pmc_summary.json "
-                       "(2 steps; FETCH_SIZE raw — dword gathers are uncalibrated on gfx950, wide streams read 1/2)"}
-        except Exception:
-            pass
+        gb_step = ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION * B
+        gating = "" if cfg.num_gen_update == 1 else f", D update every {cfg.num_gen_update} iterations (FLOPs averaged over the cycle)"
         line = {
-            "metric": "videos/sec per G+D step, 16x64x64 RGB+depth", "value": vps, "unit": "videos/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "metric": "videos/sec per G+D step, 16x64x64 RGB+depth" if cfg.channel == 1 else "videos/sec per G+D step, 16x64x64 RGB+flow",
+            "value": vps, "unit": "videos/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config/{a.config}.yml G+D step (trainer.py:279-363), as-written schedule, fp32",
-                       "per_gpu_batch": B, "global_batch": B * world, "clip": "16x64x64 RGB + geometry",
+            "config": {"workload": f"config/{a.config}.yml G+D iteration (trainer.py:279-363), as-written schedule, fp32{gating}",
+                       "per_gpu_batch": B, "global_batch": B * world, "clip": f"16x64x64 RGB + {cfg.channel}-channel {cfg.geometric_info}",
                        "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup)},
-            "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                         "flops_per_video_step": f_step, "dominant_kernel": probe},
+            "roofline": {"bound": "mfma", "achieved": probe["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": probe["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": committed_traffic(B),
+                         "kernel": probe,
+                         "step": {"achieved": step_tflops, "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS, "flops_per_video_step": f_step},
+                         "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,
+                                 "frac": gb_step / per_step / PEAK_HBM_GBPS}},
             "cpu_baseline": cpu,
             "minimal_schedule": minimal,
             "losses_last_step": losses,

@@ -89,14 +89,38 @@ CONFIGS: Dict[str, StepConfig] = {
         lr=dict(ggen=2e-4, cgen=2e-4, idis=2e-4, vdis=2e-4, gdis=2e-4), decay=dict(_DECAY)),
 }
 
-# Conv / conv-transpose / GRU FLOPs (2*MACs) for ONE video through ONE as-written
-# G+D step, and with the dead D-phase generator backward elided.
-FLOPS_PER_VIDEO_STEP = {
-    "debug-isogd-depth": (134.44e9, 96.75e9),
-    "isogd-depth": (166.12e9, 128.33e9),
-    "surreal-depth1": (188.31e9, 142.41e9),
-    "isogd-flow": (165.41e9, 127.29e9),
-    # torch.utils.flop_counter on a CPU restatement of the step (reproduces 166.12e9 for isogd-depth); minimal = as-written
-    # minus the dead generator backward (2 x 25.83e9 generator forward)
-    "surreal-segm": (204.08e9, 152.4e9),
+# Conv / conv-transpose / GRU FLOPs (2*MACs) of ONE forward pass of each model per video, in GFLOP (SURVEY §8(d),
+# BASELINE.md §4; torch.utils.flop_counter on the CPU restatement reproduces them): g = ggen, c = cgen, i / v / d = the
+# image / video / gradient discriminators, d1 = the first convolution(s) of the three discriminators together (they
+# have no data gradient when the input is a real batch).
+FORWARD_GFLOP = {
+    "debug-isogd-depth": dict(g=3.268, c=15.495, i=0.139, v=1.251, d=1.058, d1=0.170),
+    "isogd-depth": dict(g=3.268, c=15.495, i=0.139, v=4.784, d=1.058, d1=0.287),
+    "surreal-depth1": dict(g=7.318, c=15.495, i=0.139, v=4.784, d=1.058, d1=0.287),
+    "isogd-flow": dict(g=3.301, c=15.571, i=0.140, v=4.838, d=1.108, d1=0.380),
+    "surreal-segm": dict(g=7.6, c=18.23, i=0.16, v=3.1, d=1.9, d1=2.2),
 }
+
+
+def flops_per_video_iteration(cfg: "StepConfig", elide_dead_backward: bool = False) -> float:
+    """Algorithmic FLOPs of one trainer iteration (trainer.py:279-363) per video, averaged over the update-gating cycle.
+
+    forward            : ggen x2, cgen x2, every discriminator x3                           2G + 3D
+    D-phase backward   : D(real) wgrad + dgrad past the first convs, D(fake) wgrad + dgrad,   (2D - d1) + 2D + 2G
+                         and — the fakes are not detached — the generators' wgrad + dgrad     [every num_gen_update-th iteration]
+    G-phase backward   : the discriminators the loss uses (hinge ignores gdis), generators    2 D_g + 2G   [every num_dis_update-th]
+    `elide_dead_backward` drops the D phase's generator backward and the data gradient of the fakes' first convs."""
+    f = FORWARD_GFLOP[cfg.name]
+    G, D = f["g"] + f["c"], f["i"] + f["v"] + f["d"]
+    Dg = D if cfg.loss == "adversarial-loss" else f["i"] + f["v"]
+    fwd = 2 * G + 3 * D
+    bwd_d = (2 * D - f["d1"]) + 2 * D + 2 * G
+    if elide_dead_backward:
+        bwd_d -= 2 * G + f["d1"]
+    bwd_g = 2 * Dg + 2 * G
+    return (fwd + bwd_d / cfg.num_gen_update + bwd_g / cfg.num_dis_update) * 1e9
+
+
+# one forward of every model touches ~0.158 GB of conv tensors per video (11.04 GB at B = 70, fp32); the iteration's
+# multiplicities make that ~1.06 GB per video (SURVEY §8(d)): the algorithmic HBM floor the step's traffic is held against
+ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION = 1.06

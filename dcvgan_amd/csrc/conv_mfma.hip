@@ -35,6 +35,8 @@ namespace dcv {
 
 thread_local char g_err[512] = {0};
 std::atomic<uint64_t> g_launches{0};
+thread_local char g_last_kernel[160] = {0};   // diagnostics: the GEMM kernel instance of the calling thread's last conv call
+#define DCV_NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -99,6 +101,11 @@ struct GatherArgs {
     // {sum, sum of squares} over the tile's positions (fp32, <= 256 terms each; combined in fp64 by the BN op)
     float* stat;
     int32_t stat_ntm, stat_cls;
+    // data gradients only: y *= act'(gate[same element]) — the (Leaky)ReLU derivative of the layer that produced this
+    // conv's input, taken from that input itself (gate has y's shape and strides); nullptr = off
+    const float* gate;
+    float gate_slope;
+    int32_t pad3;
 };
 
 // up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
@@ -137,7 +144,7 @@ __device__ __forceinline__ uint32_t dim_mask(const DimTaps t, int o, int shift) 
 template <int TOC, int TM, int ACT, bool GENERIC>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TOC][TM], const __amdgpu_buffer_rsrc_t yrs, const uint32_t (&voff)[TM],
                                             const int ocw, const int lhi, const int OC, const uint32_t y_sc4, const int act, const float slope,
-                                            const bool accumulate) {
+                                            const bool accumulate, const __amdgpu_buffer_rsrc_t grs, const bool gated, const float gslope) {
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -151,6 +158,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TOC][TM], const 
                 if constexpr (GENERIC) {
                     if (ocw + ocr + 4 * lhi >= OC) vo = 0x80000000u;
                     if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, vo, soff, 0));
+                    if (gated) v *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo, soff, 0)) > 0.f ? 1.f : gslope;
                     v = apply_act(v, act, slope);
                 } else {
                     if constexpr (ACT == DCV_ACT_LEAKY) v = v > 0.f ? v : v * slope;
@@ -182,12 +190,14 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgs& a, const f32x1
     uint32_t voff[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) voff[j] = out_voffset(a, m0 + mcol0 + j * 32 + l31, n0, lhi, y_sc4);
-    if (OC == OCp && !accumulate) {
-        if (act == DCV_ACT_NONE) store_tiles<TOC, TM, DCV_ACT_NONE, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false);
-        else if (act == DCV_ACT_LEAKY) store_tiles<TOC, TM, DCV_ACT_LEAKY, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false);
-        else store_tiles<TOC, TM, DCV_ACT_TANH, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false);
+    const bool gated = a.gate != nullptr;
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gated ? a.gate : a.y) + a.y_off + (int64_t)n0 * a.y_sn, 0, 0x80000000u, 0x00020000);
+    if (OC == OCp && !accumulate && !gated) {
+        if (act == DCV_ACT_NONE) store_tiles<TOC, TM, DCV_ACT_NONE, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false, grs, false, 0.f);
+        else if (act == DCV_ACT_LEAKY) store_tiles<TOC, TM, DCV_ACT_LEAKY, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false, grs, false, 0.f);
+        else store_tiles<TOC, TM, DCV_ACT_TANH, false>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, false, grs, false, 0.f);
     } else {
-        store_tiles<TOC, TM, 0, true>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, accumulate);
+        store_tiles<TOC, TM, 0, true>(acc, yrs, voff, ocw, lhi, OC, y_sc4, act, slope, accumulate, grs, gated, a.gate_slope);
     }
 }
 
@@ -420,6 +430,7 @@ __global__ __launch_bounds__(256, 3) void gather_gemm_kernel(const GatherArgs a)
                     float v = acc[i][j][r];
                     float* p = yb + (int64_t)oc * a.y_sc;
                     if (a.accumulate) v += *p;
+                    if (a.gate) v *= a.gate[p - a.y] > 0.f ? 1.f : a.gate_slope;
                     *p = apply_act(v, a.act, a.slope);
                 }
             }
@@ -836,6 +847,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GatherArgsPack
         float* q = yb + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
         float x = v[e];
         if (accumulate) x += *q;
+        if (a.gate) x *= a.gate[q - a.y] > 0.f ? 1.f : a.gate_slope;
         *q = apply_act(x, act, slope);
     }
 }
@@ -1716,6 +1728,7 @@ struct TileCfg {
 
 static TileCfg pick_gather_tile(int OC) {
     if (OC <= 4) return {4, 64};  // thin_gather_kernel
+    if (OC > 64 && OC % 128 != 0 && OC % 64 == 0 && OC <= 448) return {64, 256};   // 192, 320, 448: no padded quarter tile (ggen ngf 96)
     if (OC > 64) return {128, 128};
     if (OC > 32) return {64, 256};
     return {32, 256};
@@ -1768,6 +1781,8 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     else if (tc.bn == 64) DCV_LAUNCH_DMA(2, 2, 1, 4)
     else DCV_LAUNCH_DMA(1, 2, 1, 4)
 #undef DCV_LAUNCH_DMA
+    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s> (%d x %d tile, %d class%s in one launch%s)", tc.bn == 128 ? "2, 2, 2, 2" : tc.bn == 64 ? "2, 2, 1, 4" : "1, 2, 1, 4",
+                    ds ? "true" : "false", pt ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "");
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
@@ -1785,8 +1800,10 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                       int RC, int OC, int64_t ws_o, int64_t ws_r, int KH, int KW,
                       const std::vector<GatherClass>& classes, int act, float slope, int accumulate,
                       void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
-                      float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, const dcv_wpack* pack = nullptr) {
+                      float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, const dcv_wpack* pack = nullptr,
+                      const float* gate = nullptr, float gate_slope = 0.f) {
     const TileCfg tc = pick_gather_tile(OC);
+    if (gate && tc.bn == 4) return fail(DCV_EUNSUPPORTED, "%s: the gated epilogue is not built into the thin (OC <= 4) kernels", tag);
     // packed weights: in the caller's buffer when one is given (and already valid when pack->ready), else in `ws`
     char* const pk_base = pack && pack->buf ? reinterpret_cast<char*>(pack->buf) : nullptr;
     const bool pk_ready = pk_base && pack->ready;
@@ -1980,6 +1997,8 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.slab = slab;
         a.kper = kper;
         a.Mp = Mp;
+        a.gate = gate;
+        a.gate_slope = gate_slope;
         a.stat = stat_ok ? stat : nullptr;
         a.stat_ntm = stat_ntm;
         a.stat_cls = stat_ci++;
@@ -2150,6 +2169,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             }
         }
         if (rows_kind) {
+            DCV_NOTE_KERNEL("thin_rows_kernel (OC %d, kind %d)", OC, rows_kind);
             if (npack > 0) {
                 int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
                 if (rcp != DCV_OK) return rcp;
@@ -2166,7 +2186,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             continue;
         }
         // <= 4 gathered channels, many output channels, 3x3 / unit stride / 64-wide rows: the register-resident form
-        if (tc.bn != 4 && RC <= 4 && KS2 == 1 && xd.sw == 1 && c.taps[0].n == 1 && c.taps[1].n == 3 && c.taps[2].n == 3 &&
+        if (tc.bn != 4 && !gate && RC <= 4 && KS2 == 1 && xd.sw == 1 && c.taps[0].n == 1 && c.taps[1].n == 3 && c.taps[2].n == 3 &&
             c.taps[1].mul == 1 && c.taps[2].mul == 1 && c.o_ext[2] == 64 && c.taps[2].size == 64 && c.o_ext[1] % 4 == 0 &&
             c.out_mul[1] == 1 && c.out_mul[2] == 1 && (size_t)RC * 9 * OCp * sizeof(float) <= 48 * 1024 && !toggles().no_widen) {
             auto span3 = [](const DimTaps& t, int* dmin) {
@@ -2195,6 +2215,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                 }
                 const dim3 gw((unsigned)(M64 / 256));
                 const size_t shm = (size_t)RC * 9 * OCp * sizeof(float);
+                DCV_NOTE_KERNEL("widen_rows_kernel<%d>", RC);
                 switch (RC) {
                     case 1: hipLaunchKernelGGL(widen_rows_kernel<1>, gw, dim3(256), shm, stream, a); break;
                     case 2: hipLaunchKernelGGL(widen_rows_kernel<2>, gw, dim3(256), shm, stream, a); break;
@@ -2205,6 +2226,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                 continue;
             }
         }
+        DCV_NOTE_KERNEL("%s (%d x %d tile%s)", tc.bn == 4 ? (thin_struct ? "thin_struct_kernel" : "thin_gather_kernel") : "gather_gemm_kernel", tc.bn, tc.bm, KS2 > 1 ? ", split-K" : "");
         if (tc.bn == 4 && thin_struct) {
             const int rcps = KS2 > 1 ? kper * 16 / T : RC;   // whole channels per K split
             if (T == 4) launch_thin_struct<4>(a, OC, RC, rcps, grid, stream);
@@ -2342,6 +2364,7 @@ struct WgradTile {
 };
 static WgradTile pick_wgrad_tile(int DC, int J) {
     if (J <= 32) return WgradTile{128, 32};   // stems: few gathered channels x taps
+    if (DC > 64 && J > 64 && DC % 128 != 0 && DC % 64 == 0 && J % 128 == 0) return WgradTile{64, 128};   // 192, 320: whole 64-row LDS-DMA tiles (ggen ngf 96)
     if (DC > 64) return (J > 64) ? WgradTile{128, 128} : WgradTile{128, 64};
     if (DC > 32) return (J > 128 && (DC != 64 || J % 128 != 0)) ? WgradTile{64, 256} : WgradTile{64, 128};   // 64 x 128: the LDS-DMA form
     return (J > 128) ? WgradTile{32, 256} : WgradTile{32, 128};
@@ -2387,10 +2410,18 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     int S = 1;
     int64_t chunk = 0;
     if (dma) {   // one workgroup per CU: whole rounds of 256, >= 1024 positions each
-        S = (512 + tiles - 1) / tiles;
+        const int slots = 256, target = 512;                          // one workgroup per CU; two rounds
+        S = (target + tiles - 1) / tiles;
         const int64_t maxs = (M64 + 1023) / 1024;
         if (S > maxs) S = (int)maxs;
         if (S < 1) S = 1;
+        {   // tile counts that are not powers of two (ngf 96): among the slab counts near S take the one whose last round is fullest
+            auto eff = [&](int s_) { const int64_t wg = (int64_t)tiles * s_; return (double)wg / (double)((wg + slots - 1) / slots * slots); };
+            int best = S;
+            for (int c = std::max(1, S - S / 3); c <= S + (S + 1) / 2 && c <= maxs; ++c)
+                if (eff(c) > eff(best) + 0.04) best = c;
+            S = best;
+        }
         chunk = ((M64 + S - 1) / S + 63) / 64 * 64;
         // its padding encoding needs the gathered operand's block-relative byte offsets below 2^30
         const int64_t per = (int64_t)dd.d * dd.h * dd.w;
@@ -2483,6 +2514,7 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
             a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
         }
     }
+    DCV_NOTE_KERNEL("%s (%d x %d tile, %d slabs)", dma && a.log2nd >= 0 ? (tc.bd == 128 ? "wgrad_dma_kernel<2>" : "wgrad_dma_kernel<1>") : "wgrad_gemm_kernel", tc.bd, tc.bj, S2);
     if (dma && a.log2nd >= 0) {
         if (tc.bd == 128) hipLaunchKernelGGL(wgrad_dma_kernel<2>, dim3(tiles, S2), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(tiles, S2), dim3(256), 0, stream, a);
@@ -2545,6 +2577,7 @@ int dcv_debug_read_stamps(unsigned long long* host, int nblocks) {
 #endif
 
 const char* dcv_last_error(void) { return g_err; }
+const char* dcv_debug_last_kernel(void) { return g_last_kernel; }
 int dcv_version(void) { return 1; }
 uint64_t dcv_launch_count(void) { return g_launches.load(); }
 
@@ -2553,7 +2586,7 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
                          float* out, const dcv_dims5* yd, int act, float slope, int accumulate,
                          void* ws, size_t ws_bytes, void* stream, size_t* need_only,
                          float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr,
-                         const dcv_wpack* pack = nullptr, size_t* pack_need = nullptr) {
+                         const dcv_wpack* pack = nullptr, size_t* pack_need = nullptr, const float* gate = nullptr, float gate_slope = 0.f) {
     // xd = module input dims, yd = module output dims, always.
     int rc = check_geom(g, xd, yd, "conv");
     if (rc != DCV_OK) return rc;
@@ -2610,7 +2643,7 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
         if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
         return run_gather(a_, src, out, dst, w, RC, OC, ws_o, ws_r, k[1], k[2], cls, act, slope, accumulate, ws, ws_bytes, st,
                           which == 0 ? (g->transposed ? "convT_fwd" : "conv_fwd") : (g->transposed ? "convT_bwd_data" : "conv_bwd_data"),
-                          stat, stat_bytes, stat_parts, pack);
+                          stat, stat_bytes, stat_parts, pack, gate, gate_slope);
     }
     return fail(DCV_EINVAL, "conv: bad dispatch");
 }
@@ -2658,6 +2691,16 @@ int dcv_conv_forward_stats(const dcv_conv_geom* g, const float* x, const dcv_dim
 int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd,
                            int accumulate, const dcv_wpack* pack, void* ws, size_t ws_bytes, void* stream) {
     return conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pack);
+}
+
+int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd,
+                                 int accumulate, const float* x, const dcv_dims5* xd, int act, float slope, const dcv_wpack* pack,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !xd || !dxd) return fail(DCV_EINVAL, "conv_backward_data_gated: null pointer");
+    if (act != DCV_ACT_LEAKY) return fail(DCV_EUNSUPPORTED, "conv_backward_data_gated: only (Leaky)ReLU derivatives can be read off the input");
+    if (!same_shape(*xd, *dxd) || xd->sn != dxd->sn || xd->sc != dxd->sc || xd->sd != dxd->sd || xd->sh != dxd->sh || xd->sw != dxd->sw)
+        return fail(DCV_EUNSUPPORTED, "conv_backward_data_gated: x and dx must share shape and strides");
+    return conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pack, nullptr, x, slope);
 }
 
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd,

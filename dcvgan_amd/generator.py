@@ -123,8 +123,8 @@ class Outconv(nn.Module):
         self.main = nn.Sequential(_convT(in_ch, out_ch, 3, 1, 1), nn.Tanh())
 
 
-def _block_forward(self, x, rng=None, out=None, grad_slot=None):
-    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out, grad_slot=grad_slot)
+def _block_forward(self, x, rng=None, out=None, grad_slot=None, act_slot=None):
+    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out, grad_slot=grad_slot, act_slot=act_slot)
 
 
 for _cls in (Inconv, DownBlock, UpBlock, Outconv):
@@ -169,7 +169,7 @@ class ColorVideoGenerator(nn.Module):
         # bufs[k] (k = 0..5): cat([up-path tensor at resolution size[k], skips[k]]); bufs[6]: cat([skips[6], z])
         bufs = [ops.ConcatBuffer(nb, ups[5 - k], widths[k], (size[k], size[k]), x.device) for k in range(6)]
         bufs.append(ops.ConcatBuffer(nb, widths[6], self.dim_z, (size[6], size[6]), x.device))
-        skips = [self.inconv(x, rng, out=bufs[0].second)]
+        skips = [self.inconv(x, rng, out=bufs[0].second, act_slot=bufs[0].slot)]
         for k, blk in enumerate(self.down_blocks):
             dst = bufs[k + 1].second if k + 1 < 6 else bufs[6].first
             skips.append(blk(skips[-1], rng, out=dst, grad_slot=bufs[k].slot))   # skips[k] lives in bufs[k].second

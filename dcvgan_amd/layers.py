@@ -66,10 +66,11 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, part
                       num_batches_tracked=bn.num_batches_tracked if training else None)
 
 
-def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None) -> torch.Tensor:
+def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_slot=None) -> torch.Tensor:
     """`out`: destination view for the sequence's LAST fused op (a concat-buffer slice), when that
     op is a conv(+act) or a BatchNorm group.  `grad_slot`: ops.GradSlot of the concat buffer that holds x
-    (x is a skip tensor): passed to the FIRST convolution, whose data gradient then accumulates into it."""
+    (x is a skip tensor): passed to the FIRST convolution, whose data gradient then accumulates into it.
+    `act_slot`: ops.GradSlot of the concat buffer `out` belongs to, for a conv + (Leaky)ReLU that ends the sequence."""
     layers = list(seq)
     i, n = 0, len(layers)
     pending = None   # BatchNorm partial sums left by the conv that produced x (conv -> BN pairs in training mode)
@@ -79,7 +80,8 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None) -> t
         if isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None
             if fused is not None:
-                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None, grad_slot=grad_slot if i == 0 else None)
+                x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None, grad_slot=grad_slot if i == 0 else None,
+                             act_slot=act_slot if i + 2 >= n else None)
                 _tap(x, fused)
                 i += 2
             else:

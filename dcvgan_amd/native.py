@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdcvgan_hip.so")
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
+DCV_EUNSUPPORTED = -4
 
 
 class NativeError(RuntimeError):
@@ -52,12 +53,14 @@ _SIGS = {
     "dcv_version": (C.c_int, []),
     "dcv_launch_count": (C.c_uint64, []),
     "dcv_debug_kernel_info": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "dcv_debug_last_kernel": (C.c_char_p, []),
     "dcv_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_conv_packed_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
     "dcv_conv_stats_bytes": (C.c_size_t, [_G, _D, _D]),
     "dcv_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _P, C.c_size_t, _P]),
+    "dcv_conv_backward_data_gated": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
     "dcv_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "dcv_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),

@@ -125,6 +125,7 @@ class _PackCache:
 
 _USE_PACK_CACHE = os.environ.get("DCV_NO_PACK_CACHE") is None
 _SKIP_ACCUMULATE = os.environ.get("DCV_NO_SKIP_ACCUMULATE") is None
+_GATED_DGRAD = os.environ.get("DCV_NO_GATED_DGRAD") is None
 
 
 def _pack_of(w):
@@ -138,9 +139,12 @@ def _pack_of(w):
 
 class _Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None, act_slot=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
         ctx.grad_slot = grad_slot
+        ctx.act_slot = act_slot if (act_slot is not None and act == ACT_LEAKY) else None
+        if ctx.act_slot is not None:
+            ctx.act_slot.act, ctx.act_slot.act_applied = (act, slope), False
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
         if not w.is_contiguous():
@@ -176,7 +180,10 @@ class _Conv(Function):
         g = ctx.g
         L = lib()
         dy = _dense(dy)
-        if ctx.act != ACT_NONE:
+        fused_away = ctx.act_slot is not None and ctx.act_slot.act_applied    # the consumer's data gradient already applied act'
+        if ctx.act_slot is not None:
+            ctx.act_slot.act_applied = False
+        if ctx.act != ACT_NONE and not fused_away:
             dz = _empty(y.shape, y.device)
             dyd, yd, dzd = dims5(dy), dims5(y), dims5(dz)   # y may be a strided concat-buffer slice; dz is dense
             check(L.dcv_act_backward(ptr(dy), C.byref(dyd), ptr(y), C.byref(yd), ptr(dz), C.byref(dzd), ctx.act, ctx.slope, stream_ptr()), "dcv_act_backward")
@@ -194,8 +201,20 @@ class _Conv(Function):
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1)
             wsp, wsn = _ws("conv", need, x.device)
             pk = ctx.pack.get(w, 1, g, dx, dy, dxd, dyd) if ctx.pack is not None else None
-            check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), int(into is not None),
-                                           C.byref(pk) if pk is not None else None, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
+            pkp = C.byref(pk) if pk is not None else None
+            rc = N.DCV_EUNSUPPORTED
+            if into is not None and slot.act is not None and _GATED_DGRAD and tuple(x.stride()) == tuple(into.stride()):
+                # ... and the derivative of the activation that produced x, read off x, in the same epilogue
+                xd_ = dims5(x)
+                rc = L.dcv_conv_backward_data_gated(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), 1, ptr(x), C.byref(xd_),
+                                                    slot.act[0], slot.act[1], pkp, wsp, wsn, stream_ptr())
+                if rc == 0:
+                    slot.act_applied = True
+                elif rc != N.DCV_EUNSUPPORTED:
+                    check(rc, "dcv_conv_backward_data_gated")
+            if rc == N.DCV_EUNSUPPORTED:
+                check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), int(into is not None),
+                                               pkp, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:
@@ -203,14 +222,15 @@ class _Conv(Function):
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None, act_slot=None):
     """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries.
     `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into.
-    `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection), see GradSlot."""
-    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot)
+    `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection), see GradSlot.
+    `act_slot`: ConcatBuffer.slot of the buffer this conv + (Leaky)ReLU writes its output into (`out` is its second slice)."""
+    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot, act_slot)
 
 
 # --------------------------------------------------------------------------- #
@@ -410,10 +430,15 @@ class GradSlot:
     runs first (it was recorded later) and leaves its slice here; the data gradient of the tensor's other consumer
     then accumulates into that slice (`dcv_conv_backward_data(accumulate=1)`) instead of producing a second tensor
     for autograd to add.  If the order is ever different the slot is simply empty and nothing changes."""
-    __slots__ = ("g",)
+    __slots__ = ("g", "act", "act_applied")
 
     def __init__(self):
         self.g = None
+        # set by the conv + (Leaky)ReLU that PRODUCED the skip tensor (ops.conv(..., act_slot=)): its activation, whose
+        # derivative the consumer's data gradient can apply from the tensor itself (dcv_conv_backward_data_gated) — the
+        # producer then skips its own derivative pass (act_applied)
+        self.act = None
+        self.act_applied = False
 
     def take(self, x):
         g, self.g = self.g, None

@@ -63,6 +63,9 @@ int dcv_version(void);
 /* number of kernel launches issued through this library so far (tests use it to
  * prove the HIP path, not a fallback, did the work) */
 uint64_t dcv_launch_count(void);
+/* diagnostics: which GEMM kernel instance the calling thread's last dcv_conv_* call launched (bench.py / tools label
+ * their per-layer timings with it) */
+const char* dcv_debug_last_kernel(void);
 /* diagnostics text: resident workgroups/CU, registers, LDS of every GEMM kernel (needs a GPU) */
 int dcv_debug_kernel_info(char* buf, size_t n);
 
@@ -99,6 +102,15 @@ int dcv_conv_forward_stats(const dcv_conv_geom* g, const float* x, const dcv_dim
 int dcv_conv_backward_data(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w,
                            float* dx, const dcv_dims5* dxd, int accumulate, const dcv_wpack* pack,
                            void* ws, size_t ws_bytes, void* stream);
+/* backward_data followed by the (Leaky)ReLU derivative of the layer that PRODUCED this conv's input, read off that
+ * input itself: dx = (accumulate ? dx : 0) + conv^T(dy, w), then dx *= (x > 0 ? 1 : slope).  x must have dx's shape and
+ * strides.  Replaces the separate derivative pass of an nn.Conv2d + nn.LeakyReLU pair whose output feeds this conv
+ * (Inconv -> DownBlock 0, generator.py:173-176,203-207).  DCV_EUNSUPPORTED (before any launch) for geometries whose
+ * kernels lack the gated epilogue: the caller then runs the two steps separately. */
+int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w,
+                                 float* dx, const dcv_dims5* dxd, int accumulate,
+                                 const float* x, const dcv_dims5* xd, int act, float slope, const dcv_wpack* pack,
+                                 void* ws, size_t ws_bytes, void* stream);
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd,
                              const float* dy, const dcv_dims5* dyd, float* dw,
                              void* ws, size_t ws_bytes, void* stream);

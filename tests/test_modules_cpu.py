@@ -12,7 +12,7 @@ from dcvgan_amd import discriminator as D
 from dcvgan_amd import generator as Gm
 from dcvgan_amd import loss as Lm
 from dcvgan_amd import trainer, util
-from dcvgan_amd.configs import CONFIGS, FLOPS_PER_VIDEO_STEP
+from dcvgan_amd.configs import CONFIGS, flops_per_video_iteration
 from tests import goldenio as G
 
 
@@ -105,7 +105,11 @@ def test_configs_restated():
     assert (s.batchsize, s.loss, s.num_gen_update, s.width["ggen"], s.width["gdis"]) == (100, "hinge-loss", 2, 96, 32)
     f = CONFIGS["isogd-flow"]
     assert (f.channel, f.geometric_info, f.noise_sigma["idis"]) == (2, "optical-flow", 0.2)
-    assert FLOPS_PER_VIDEO_STEP["isogd-depth"][0] == 166.12e9
+    # BASELINE.md §4 / SURVEY §8(d): as-written and "minimal" GFLOP per video and iteration
+    for name, want, want_min in (("debug-isogd-depth", 134.44, 96.75), ("isogd-depth", 166.12, 128.33), ("isogd-flow", 165.41, 127.29)):
+        assert abs(flops_per_video_iteration(CONFIGS[name]) / 1e9 - want) < 0.05 and abs(flops_per_video_iteration(CONFIGS[name], True) / 1e9 - want_min) < 0.05
+    # surreal-depth1 updates the discriminators every 2nd iteration (surreal-depth1.yml:30): 188.31 with every backward, 153.67 on average
+    assert abs(flops_per_video_iteration(s) / 1e9 - 153.67) < 0.05
 
 
 def test_checkpoint_interchange_fixture():

@@ -130,6 +130,20 @@ def test_conv_backward_data_accumulates_into_a_slice(dev, case):
     N.check(L.dcv_conv_backward_data(C.byref(geom), ptr(dy_d), C.byref(dyd), ptr(w_d), ptr(dx), C.byref(dxd), 1, None, ptr(ws), need, stream_ptr()), "accumulate")
     assert rel(wide_d, want) < 1e-5
     assert torch.equal(wide_d[:, :5].cpu(), wide[:, :5])          # the neighbouring channels are untouched
+    # dcv_conv_backward_data_gated: the same, then times the LeakyReLU derivative read off the conv's own input, which
+    # sits in the matching slice of a second buffer of the same layout (Inconv -> DownBlock 0 of the U-Net)
+    xin = torch.randn(wide.shape, generator=g)
+    want2 = wide.clone(); want2[:, 5:] = (wide[:, 5:] + gx) * torch.where(xin[:, 5:] > 0, 1.0, 0.01)
+    wide2_d, xin_d = wide.to(dev), xin.to(dev)
+    dx2, x2 = wide2_d[:, 5:], xin_d[:, 5:]
+    xd2 = dims5(x2)
+    rc = L.dcv_conv_backward_data_gated(C.byref(geom), ptr(dy_d), C.byref(dyd), ptr(w_d), ptr(dx2), C.byref(dxd), 1, ptr(x2), C.byref(xd2),
+                                        ops.ACT_LEAKY, 0.01, None, ptr(ws), need, stream_ptr())
+    if cin <= 4:
+        assert rc == N.DCV_EUNSUPPORTED        # thin kernels: the caller falls back to the two separate steps
+    else:
+        assert rc == 0, L.dcv_last_error()
+        assert rel(wide2_d, want2) < 1e-5 and torch.equal(wide2_d[:, :5].cpu(), wide[:, :5])
 
 
 def test_conv_fused_act(dev):
