@@ -755,12 +755,16 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
             if constexpr (PATCH) {
                 if (ks < NS) DCV_ISSUE_X(itn, soffn, buf ^ 1, ks)
             } else {
+                if constexpr (XPT >= 8) {
 #pragma unroll
-                for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_X(itn, soffn, buf ^ 1, ks * (XPT / 8) + q)
+                    for (int q = 0; q < XPT / 8; ++q) DCV_ISSUE_X(itn, soffn, buf ^ 1, ks * (XPT / 8) + q)
+                } else {   // 64-position tiles: XPT = 4 rows per wave, one in every other k-step
+                    if ((ks & 1) == 0) DCV_ISSUE_X(itn, soffn, buf ^ 1, (ks / 2) < XPT ? ks / 2 : 0)
+                }
             }
             __builtin_amdgcn_sched_group_barrier(0x100, TOC + TM, 0);   // next step's fragments first,
             __builtin_amdgcn_sched_group_barrier(0x008, TOC * TM, 0);   // then this step's MFMAs,
-            if (!PATCH || ks < NS) __builtin_amdgcn_sched_group_barrier(0x010, PATCH ? 1 : XPT / 8, 0);   // then the DMA issues in their shadow
+            if (PATCH ? ks < NS : (XPT >= 8 || (ks & 1) == 0)) __builtin_amdgcn_sched_group_barrier(0x010, PATCH ? 1 : (XPT >= 8 ? XPT / 8 : 1), 0);   // then the DMA issues in their shadow
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -1666,10 +1670,12 @@ static std::map<std::string, DevTable> g_tables;   // keys start with the device
 // A/B switches for tools/ (variant off when the variable is set); read once, not per call
 struct Toggles {
     bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64;
+    int half_m;
     Toggles() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
         no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64");
+        half_m = getenv("DCV_HALF_M") ? atoi(getenv("DCV_HALF_M")) : -1;
     }
 };
 static const Toggles& toggles() {
@@ -1777,11 +1783,14 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
         else if (pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, true>), grid, dim3(256), 0, stream, pend);      \
         else hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, false>), grid, dim3(256), 0, stream, pend);             \
     }
-    if (tc.bn == 128) DCV_LAUNCH_DMA(2, 2, 2, 2)
+    if (tc.bn == 128 && tc.bm == 64) DCV_LAUNCH_DMA(2, 1, 2, 2)
+    else if (tc.bn == 64 && tc.bm == 128) DCV_LAUNCH_DMA(2, 1, 1, 4)
+    else if (tc.bn == 128) DCV_LAUNCH_DMA(2, 2, 2, 2)
     else if (tc.bn == 64) DCV_LAUNCH_DMA(2, 2, 1, 4)
     else DCV_LAUNCH_DMA(1, 2, 1, 4)
 #undef DCV_LAUNCH_DMA
-    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s> (%d x %d tile, %d class%s in one launch%s)", tc.bn == 128 ? "2, 2, 2, 2" : tc.bn == 64 ? "2, 2, 1, 4" : "1, 2, 1, 4",
+    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s> (%d x %d tile, %d class%s in one launch%s)",
+                    tc.bn == 128 ? (tc.bm == 64 ? "2, 1, 2, 2" : "2, 2, 2, 2") : tc.bn == 64 ? (tc.bm == 128 ? "2, 1, 1, 4" : "2, 2, 1, 4") : "1, 2, 1, 4",
                     ds ? "true" : "false", pt ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "");
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
@@ -1802,7 +1811,23 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                       void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
                       float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, const dcv_wpack* pack = nullptr,
                       const float* gate = nullptr, float gate_slope = 0.f) {
-    const TileCfg tc = pick_gather_tile(OC);
+    TileCfg tc = pick_gather_tile(OC);
+    if (tc.bn >= 64) {
+        // Tail regime: the op's workgroups (all classes, one launch) make a little more than a whole number of rounds of
+        // the chip's 1024 resident workgroups, or do not fill one round.  Tiles of half as many positions then waste half as
+        // much (a partial round of short workgroups) and fill an under-filled chip; measured on the 4x4 / 8x8-spatial
+        // layers.  DCV_HALF_M = 0 / 1 forces the choice for A/B runs.
+        int64_t W = 0;
+        for (const GatherClass& c : classes) {
+            if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+            const int64_t Mc = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+            W += ((OC + tc.bn - 1) / tc.bn) * ((Mc + tc.bm - 1) / tc.bm);
+        }
+        const double rounds = (double)W / 1024.0, frac = rounds - (double)(int64_t)rounds;
+        bool half = (rounds > 0.4 && rounds < 1.0) || (rounds >= 1.0 && rounds < 3.0 && frac > 0.15 && frac < 0.55);
+        if (toggles().half_m >= 0) half = toggles().half_m != 0;
+        if (half) tc.bm /= 2;
+    }
     if (gate && tc.bn == 4) return fail(DCV_EUNSUPPORTED, "%s: the gated epilogue is not built into the thin (OC <= 4) kernels", tag);
     // packed weights: in the caller's buffer when one is given (and already valid when pack->ready), else in `ws`
     char* const pk_base = pack && pack->buf ? reinterpret_cast<char*>(pack->buf) : nullptr;
@@ -2233,6 +2258,8 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             else if (T == 9) launch_thin_struct<9>(a, OC, RC, rcps, grid, stream);
             else launch_thin_struct<16>(a, OC, RC, rcps, grid, stream);
         } else if (tc.bn == 4) hipLaunchKernelGGL(thin_gather_kernel, grid, dim3(256), 0, stream, a);
+        else if (tc.bn == 128 && tc.bm == 64) launch_gather<2, 1, 2, 2>(a, grid, stream);
+        else if (tc.bn == 64 && tc.bm == 128) launch_gather<2, 1, 1, 4>(a, grid, stream);
         else if (tc.bn == 128) launch_gather<2, 2, 2, 2>(a, grid, stream);
         else if (tc.bn == 64) launch_gather<2, 2, 1, 4>(a, grid, stream);
         else launch_gather<1, 2, 1, 4>(a, grid, stream);
@@ -2620,8 +2647,9 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
             ws_o = T;
             ws_r = (int64_t)OC * T;
         }
-        if (stat_need) {   // upper bound of the fused-BN partial-sum buffer
-            const TileCfg tc = pick_gather_tile(OC);
+        if (stat_need) {   // upper bound of the fused-BN partial-sum buffer (run_gather may halve the position tile)
+            TileCfg tc = pick_gather_tile(OC);
+            if (tc.bn >= 64) tc.bm /= 2;
             const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
             int64_t ntm = 0, ncls = 0;
             for (const GatherClass& c : cls) {

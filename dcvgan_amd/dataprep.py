@@ -4,8 +4,9 @@ data-parallel trainer (560 clips/step at 8 GPUs) is not host-bound.  The DataLoa
 hand over disk-order frames — uint8 (B,T,H,W,C) for images, fp32 (B,T,H,W,2) flow, fp32 (B,T,H,W)
 SURREAL depth — ideally from pinned memory with `non_blocking=True`.
 
-The reference's dataset module cannot be imported here (cv2 / skvideo), so these are restatements of
-its formulas, pinned by the assertions of its own tests (test_dataset.py:32-95), not by executing it.
+Pinned by execution: tests/golden/make_dataset_golden.py imports the reference's dataset module (cv2 / skvideo
+stubbed, the image reader shimmed over PIL) and stores what `VideoDataset.__getitem__` returns for the reference's
+own mock dataset and for a SURREAL-format one; tests/test_dataprep_gpu.py compares these kernels byte for byte.
 """
 from __future__ import annotations
 
