@@ -35,7 +35,7 @@ xg_in, xc_in = r32["xg"].detach(), r32["xc"].detach()
 def d_only(dtype):
     st = FW.states_of({n: models[n].cpu() for n in ("idis", "vdis", "gdis")}, dtype)
     rng = O.ReplayRng([(k, v.to(dtype)) for k, v in dlog]) if dlog is not None else O.TorchRng()
-    xg = xg_in.to(dtype).requires_grad_(True); xc = xc_in.to(dtype).requires_grad_(True)
+    xg = xg_in.detach().clone().to(dtype).requires_grad_(True); xc = xc_in.detach().clone().to(dtype).requires_grad_(True)
     yi = O.idis_forward(st["idis"], xg[:, :, t], xc[:, :, t], cfg.use_noise["idis"], cfg.noise_sigma["idis"], rng, True)
     yv = O.vdis_forward(st["vdis"], xg, xc, cfg.use_noise["vdis"], cfg.noise_sigma["vdis"], rng, True)
     yg = O.gdis_forward(st["gdis"], xg, xc, cfg.use_noise["gdis"], cfg.noise_sigma["gdis"], rng, True)
@@ -53,7 +53,7 @@ r = InjectedRng(dlog)
 for m in models.values():
     m._rng = r
     m.zero_grad()
-xg = xg_in.to(dev).requires_grad_(True); xc = xc_in.to(dev).requires_grad_(True)
+xg = xg_in.detach().clone().to(dev).requires_grad_(True); xc = xc_in.detach().clone().to(dev).requires_grad_(True)
 yi = models["idis"](xg[:, :, t], xc[:, :, t]); yv = models["vdis"](xg, xc); yg = models["gdis"](xg, xc)
 trainer.build_loss(cfg).compute_gen_loss(yi, yv, yg).backward()
 print("\ndiscriminators alone on identical inputs")
