@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3   # same guide: the bf16 MFMA rate is 16x the f32 one (~2.5 PFLOP/s dense)
 PEAK_HBM_GBPS = 8000.0          # same guide, HBM3E
 
 
@@ -48,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the DP path on one GPU)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: MFMA products in bf16 with fp32 accumulation in the large GEMM kernels (tensors, weights, statistics and "
+                         "optimiser state stay fp32) — a secondary throughput line for BASELINE configs[2]/[4], not the headline")
     ap.add_argument("--minimal", action="store_true", help="also time the schedule with the dead D-phase generator backward elided (secondary line)")
     ap.add_argument("--no-minimal", action="store_true", help="(default; kept for older command lines)")
     return ap.parse_args()
@@ -80,7 +84,7 @@ def dominant_kernel_probe(models, cfg, dev):
 
 
 def committed_traffic(batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/pmc_layer.sh; FETCH_SIZE
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/round_profile.sh -> tools/dominant_pmc.py; FETCH_SIZE
     doubled for the 16-byte-per-lane operand streams as the MI355X guide prescribes) — only when it was taken at this batch."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")))
@@ -166,6 +170,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(CONFIGS[a.config], a.cpu_batch, a.cpu_steps)
 
+    native.set_precision(a.precision)
+    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     torch.manual_seed(cfg.seed)  # identical init on every rank, then made exact by a broadcast
     models = trainer.build_models(cfg, dev)
     for m in models.values():
@@ -215,7 +221,7 @@ def main():
         minimal = {"note": "NOT the headline: D-phase fakes built without a tape (StepRunner(elide_dead_backward=True)); identical parameter "
                            "updates, FLOPs = BASELINE.md 'minimal' column",
                    "value": B * world / (dt2 / a.steps), "unit": "videos/s", "ms_per_step": dt2 / a.steps * 1e3,
-                   "flops_per_video_step": f_min, "frac": f_min * (B / (dt2 / a.steps)) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+                   "flops_per_video_step": f_min, "frac": f_min * (B / (dt2 / a.steps)) / 1e12 / peak}
 
     if rank == 0:
         per_step = dt / a.steps
@@ -228,14 +234,15 @@ def main():
         line = {
             "metric": "videos/sec per G+D step, 16x64x64 RGB+depth" if cfg.channel == 1 else "videos/sec per G+D step, 16x64x64 RGB+flow",
             "value": vps, "unit": "videos/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config/{a.config}.yml G+D iteration (trainer.py:279-363), as-written schedule, fp32{gating}",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": f"config/{a.config}.yml G+D iteration (trainer.py:279-363), as-written schedule, "
+                                   + ("fp32" if a.precision == "fp32" else "bf16 MFMA products / fp32 accumulation, storage, statistics and optimiser (throughput mode)") + gating,
                        "per_gpu_batch": B, "global_batch": B * world, "clip": f"16x64x64 RGB + {cfg.channel}-channel {cfg.geometric_info}",
                        "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup)},
-            "roofline": {"bound": "mfma", "achieved": probe["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": probe["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": committed_traffic(B),
+            "roofline": {"bound": "mfma", "achieved": probe["tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": probe["tflops"] / peak, "traffic": committed_traffic(B) if a.precision == "fp32" else None,
                          "kernel": probe,
-                         "step": {"achieved": step_tflops, "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS, "flops_per_video_step": f_step},
+                         "step": {"achieved": step_tflops, "frac": step_tflops / peak, "flops_per_video_step": f_step},
                          "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,
                                  "frac": gb_step / per_step / PEAK_HBM_GBPS}},
             "cpu_baseline": cpu,

@@ -39,6 +39,20 @@ thread_local char g_last_kernel[160] = {0};   // diagnostics: the GEMM kernel in
 #define DCV_NOTE_KERNEL(...) snprintf(g_last_kernel, sizeof(g_last_kernel), __VA_ARGS__)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Precision of the MFMA products in the LDS-DMA GEMM kernels: 0 = fp32 (v_mfma_f32_32x32x2_f32, the default and the only
+// mode the parity tests and the headline benchmark use), 1 = bf16 products with fp32 accumulation
+// (v_mfma_f32_32x32x16_bf16): tensors, weights, statistics and accumulators stay fp32 in HBM and LDS, the MFMA fragments
+// are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as they are read from LDS.  Throughput-only mode (BASELINE configs[2], [4]).
+std::atomic<int> g_precision{0};
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(const float (&t)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[q] = (__bf16)t[q];
+    return r;
+}
 
 #ifdef DCV_STAMP
 // diagnostic build only: per-wave cycle totals of the K-loop segments (never in the shipped library)
@@ -500,7 +514,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // data gradients, where 20-30 % of the (position, depth tap) pairs are padding.  Steps whose depth tap is
 // outside the tensor for every position of the tile are skipped outright; for the rest the tap's validity
 // is OR-ed into the per-lane voffsets (one VALU op per DMA).
-template <int TOC, int TM, int WOC, int WM, bool DSTEP, bool PATCH>
+template <int TOC, int TM, int WOC, int WM, bool DSTEP, bool PATCH, bool BF = false>
 __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
@@ -622,6 +636,19 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
         for (int k = 0; k < 8; ++k) koff[k] = PATCH ? sl16[2 * k] : 0;
     }
+    // bf16 products: a lane of half-wave lhi holds k rows 8 lhi .. 8 lhi + 7 of the step; patch form: their byte offsets
+    // inside the patch (the fp32 form's fb[] carries the odd-row tap step, which is taken back out here)
+    uint32_t koff8[BF && PATCH ? 8 : 1], fbb[BF && PATCH ? TM : 1];
+    if constexpr (BF && PATCH) {
+        typedef int32_t i32x16b __attribute__((ext_vector_type(16)));
+        const i32x16b slb = *reinterpret_cast<const i32x16b*>(a.s_local);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) koff8[q] = (uint32_t)(lhi ? slb[8 + q] : slb[q]);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fbb[j] = fb[j] - (uint32_t)(4 * lhi * a.p_dw1);
+    } else {
+        koff8[0] = 0; fbb[0] = 0;
+    }
     // W tile: float4 index f = tid + 256 j -> row f / (BN/4), column 4 (f % (BN/4)); LDS offset = 4 f floats
     uint32_t wvo[WPT];
 #pragma unroll
@@ -726,6 +753,36 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         DCV_ISSUE_W(itn, buf ^ 1)
         const float* xt = Xs + buf * 16 * BM;
         const float* wt = Ws + buf * 16 * BN;
+        if constexpr (BF) {
+            // one v_mfma_f32_32x32x16_bf16 per (i, j) covers the step's 16 k rows: the next tile's X DMAs go out first,
+            // then 8 LDS reads + 4 packed conversions per fragment
+#pragma unroll
+            for (int i = 0; i < (PATCH ? NS : XPT); ++i) DCV_ISSUE_X(itn, soffn, buf ^ 1, i)
+            bf16x8 a8[TOC], b8[TM];
+#pragma unroll
+            for (int i = 0; i < TOC; ++i) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = wt[(8 * lhi + q) * BN + (woc * TOC + i) * 32 + l31];
+                a8[i] = pack_bf16x8(t);
+            }
+#pragma unroll
+            for (int jj = 0; jj < TM; ++jj) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    t[q] = PATCH ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xt) + (fbb[PATCH ? jj : 0] + koff8[PATCH ? q : 0]))
+                                 : xt[(8 * lhi + q) * BM + (wm * TM + jj) * 32 + l31];
+                b8[jj] = pack_bf16x8(t);
+            }
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TM; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[jj], acc[i][jj], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        }
         float af[2][TOC], bf[2][TM];
 #pragma unroll
         for (int i = 0; i < TOC; ++i) af[0][i] = wt[lhi * BN + (woc * TOC + i) * 32 + l31];
@@ -1477,7 +1534,7 @@ __device__ __forceinline__ void wgrad_tile_addr(const WgradArgs& a, int m, int m
 }
 
 // TD = dense-operand row tiles per wave: 2 -> 128 x 128 tile, 1 -> 64 x 128 (64-channel layers: cgen.down0, gdis.5)
-template <int TD>
+template <int TD, bool BF = false>
 __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     constexpr int BD = 64 * TD, BJ = 128, P = 65, TILE = (BD + BJ) * P, DR = 16 * TD;   // DR: dense rows DMA'd per wave
     __shared__ float smem[2 * TILE];
@@ -1552,6 +1609,35 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         // voffsets of the tile after next: plain VALU work with no consumer inside this step, free to be
         // scheduled into the shadow of the MFMAs below (one wave per SIMD: nothing else would hide it)
         DCV_WG_ADDR(min(it + 2, nit - 1), dvon, gvon)
+        if constexpr (BF) {
+            // bf16 products: the tile's 64 positions are 4 MFMA k-blocks of 16; a lane of half-wave lhi holds positions
+            // 16 s + 8 lhi .. + 7 of its channel row.  The next tile's DR + 32 row DMAs go out first.
+#pragma unroll
+            for (int q = 0; q < 32; ++q) { if (q < DR) { DCV_WG_DROW(buf ^ 1, q < DR ? q : 0) } DCV_WG_GROW(buf ^ 1, q) }
+            const float* da0 = da - lhi;
+            const float* gb0 = gb - lhi;
+#pragma unroll
+            for (int sb = 0; sb < 4; ++sb) {
+                bf16x8 a8[TD], b8[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float t[8];
+                    if (i < TD) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) t[q] = da0[i * 32 * P + 16 * sb + 8 * lhi + q];
+                        a8[i < TD ? i : 0] = pack_bf16x8(t);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t[q] = gb0[i * 32 * P + 16 * sb + 8 * lhi + q];
+                    b8[i] = pack_bf16x8(t);
+                }
+#pragma unroll
+                for (int i = 0; i < TD; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
         float af[2][TD], bf[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) { if (i < TD) af[0][i < TD ? i : 0] = da[i * 32 * P]; bf[0][i] = gb[i * 32 * P]; }
@@ -1587,6 +1673,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
                 else if (left == 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
                 else if (left == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
             }
+        }
         }
         __builtin_amdgcn_s_setprio(0);
         STAMP(w1);
@@ -1776,12 +1863,17 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
         pend.c[0].pad0 = n;
     }
     const bool ds = pend.c[0].structured == 2, pt = pend.c[0].patch != 0;
+    const bool bfm = g_precision.load(std::memory_order_relaxed) == 1;
+#define DCV_LAUNCH_DMA1(A, B, C_, D, BF_)                                                                                     \
+    {                                                                                                                         \
+        if (ds && pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, true, BF_>), grid, dim3(256), 0, stream, pend); \
+        else if (ds) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, false, BF_>), grid, dim3(256), 0, stream, pend); \
+        else if (pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, true, BF_>), grid, dim3(256), 0, stream, pend); \
+        else hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, false, BF_>), grid, dim3(256), 0, stream, pend);        \
+    }
 #define DCV_LAUNCH_DMA(A, B, C_, D)                                                                                           \
     {                                                                                                                         \
-        if (ds && pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, true>), grid, dim3(256), 0, stream, pend);      \
-        else if (ds) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, false>), grid, dim3(256), 0, stream, pend);      \
-        else if (pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, true>), grid, dim3(256), 0, stream, pend);      \
-        else hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, false, false>), grid, dim3(256), 0, stream, pend);             \
+        if (bfm) DCV_LAUNCH_DMA1(A, B, C_, D, true) else DCV_LAUNCH_DMA1(A, B, C_, D, false)                                  \
     }
     if (tc.bn == 128 && tc.bm == 64) DCV_LAUNCH_DMA(2, 1, 2, 2)
     else if (tc.bn == 64 && tc.bm == 128) DCV_LAUNCH_DMA(2, 1, 1, 4)
@@ -1789,9 +1881,10 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     else if (tc.bn == 64) DCV_LAUNCH_DMA(2, 2, 1, 4)
     else DCV_LAUNCH_DMA(1, 2, 1, 4)
 #undef DCV_LAUNCH_DMA
-    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s> (%d x %d tile, %d class%s in one launch%s)",
+#undef DCV_LAUNCH_DMA1
+    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s%s> (%d x %d tile, %d class%s in one launch%s)",
                     tc.bn == 128 ? (tc.bm == 64 ? "2, 1, 2, 2" : "2, 2, 2, 2") : tc.bn == 64 ? (tc.bm == 128 ? "2, 1, 1, 4" : "2, 2, 1, 4") : "1, 2, 1, 4",
-                    ds ? "true" : "false", pt ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "");
+                    ds ? "true" : "false", pt ? "true" : "false", bfm ? ", bf16" : "", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "");
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
@@ -2541,10 +2634,14 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
             a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
         }
     }
-    DCV_NOTE_KERNEL("%s (%d x %d tile, %d slabs)", dma && a.log2nd >= 0 ? (tc.bd == 128 ? "wgrad_dma_kernel<2>" : "wgrad_dma_kernel<1>") : "wgrad_gemm_kernel", tc.bd, tc.bj, S2);
-    if (dma && a.log2nd >= 0) {
-        if (tc.bd == 128) hipLaunchKernelGGL(wgrad_dma_kernel<2>, dim3(tiles, S2), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(tiles, S2), dim3(256), 0, stream, a);
+    DCV_NOTE_KERNEL("%s%s (%d x %d tile, %d slabs)", dma && a.log2nd >= 0 ? (tc.bd == 128 ? "wgrad_dma_kernel<2>" : "wgrad_dma_kernel<1>") : "wgrad_gemm_kernel",
+                    dma && a.log2nd >= 0 && g_precision.load(std::memory_order_relaxed) == 1 ? " bf16" : "", tc.bd, tc.bj, S2);
+    if (dma && a.log2nd >= 0 && g_precision.load(std::memory_order_relaxed) == 1) {
+        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<1, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
+    } else if (dma && a.log2nd >= 0) {
+        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, false>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<1, false>), dim3(tiles, S2), dim3(256), 0, stream, a);
     }
     else if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);
@@ -2605,6 +2702,12 @@ int dcv_debug_read_stamps(unsigned long long* host, int nblocks) {
 
 const char* dcv_last_error(void) { return g_err; }
 const char* dcv_debug_last_kernel(void) { return g_last_kernel; }
+int dcv_set_precision(int mode) {
+    if (mode != 0 && mode != 1) return fail(DCV_EINVAL, "set_precision: 0 = fp32, 1 = bf16 MFMA products");
+    g_precision.store(mode);
+    return DCV_OK;
+}
+int dcv_get_precision(void) { return g_precision.load(); }
 int dcv_version(void) { return 1; }
 uint64_t dcv_launch_count(void) { return g_launches.load(); }
 

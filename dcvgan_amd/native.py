@@ -54,6 +54,8 @@ _SIGS = {
     "dcv_launch_count": (C.c_uint64, []),
     "dcv_debug_kernel_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dcv_debug_last_kernel": (C.c_char_p, []),
+    "dcv_set_precision": (C.c_int, [C.c_int]),
+    "dcv_get_precision": (C.c_int, []),
     "dcv_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_conv_packed_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
@@ -116,6 +118,11 @@ def lib():
 def check(rc: int, what: str):
     if rc != 0:
         raise NativeError(f"{what} failed (code {rc}): {lib().dcv_last_error().decode(errors='replace')}")
+
+
+def set_precision(mode: str):
+    """'fp32' (default) or 'bf16': bf16 MFMA products with fp32 accumulation in the large GEMM kernels (throughput mode)."""
+    check(lib().dcv_set_precision({"fp32": 0, "bf16": 1}[mode]), "dcv_set_precision")
 
 
 def launch_count() -> int:

@@ -63,6 +63,12 @@ int dcv_version(void);
 /* number of kernel launches issued through this library so far (tests use it to
  * prove the HIP path, not a fallback, did the work) */
 uint64_t dcv_launch_count(void);
+/* Precision of the MFMA products in the large GEMM kernels (process-wide): 0 = fp32 (default; the mode every parity claim
+ * and the headline benchmark refer to), 1 = bf16 products with fp32 accumulation (v_mfma_f32_32x32x16_bf16): tensors,
+ * weights, BatchNorm statistics and optimiser state stay fp32, only the MFMA fragments are rounded (RNE) as they are read
+ * from LDS.  A throughput mode for BASELINE.json's bf16 / fp16 configs; the reference itself is fp32-only. */
+int dcv_set_precision(int mode);
+int dcv_get_precision(void);
 /* diagnostics: which GEMM kernel instance the calling thread's last dcv_conv_* call launched (bench.py / tools label
  * their per-layer timings with it) */
 const char* dcv_debug_last_kernel(void);

@@ -26,6 +26,7 @@ ap.add_argument("--csv", default="")
 ap.add_argument("--filter", default="")
 ap.add_argument("--plan", default="")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
 a = ap.parse_args()
 cfg = CONFIGS[a.config]
 B = a.batch or cfg.batchsize
@@ -90,6 +91,9 @@ def timeit(fn, reps):
 
 
 Lb = lib()
+N.set_precision(a.precision)
+if a.precision == "bf16":
+    PEAK = 16 * 157.3
 rows, plan = [], []
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 totf = 0.0
@@ -157,11 +161,11 @@ if a.plan:
     json.dump({"config": a.config, "batch": B, "entries": plan}, open(a.plan, "w"), indent=1)
     sys.exit(0)
 ts = sum(tot.values())
-print("per-iteration conv time (ms): fwd %.1f dgrad %.1f wgrad %.1f total %.1f ; %.1f TF/s avg = %.3f of the fp32 MFMA peak" % (tot["fwd"], tot["dgrad"], tot["wgrad"], ts, totf / ts, totf / ts / PEAK))
+print("per-iteration conv time (ms): fwd %.1f dgrad %.1f wgrad %.1f total %.1f ; %.1f TF/s avg = %.3f of the %s MFMA peak" % (tot["fwd"], tot["dgrad"], tot["wgrad"], ts, totf / ts, totf / ts / PEAK, a.precision))
 if a.csv:
     with open(a.csv, "w") as f:
         f.write(f"# {a.config}, per-GPU batch {B}; HIP events, {a.reps} reps; launches_per_iteration follows trainer.py:279-363 (gating averaged)\n")
-        f.write("layer,op,kernel,gflop,ms,tflops,frac_of_fp32_mfma_peak,launches_per_iteration\n")
+        f.write(f"layer,op,kernel,gflop,ms,tflops,frac_of_{a.precision}_mfma_peak,launches_per_iteration\n")
         for r in rows:
             f.write('"%s",%s,"%s",%.2f,%.4f,%.1f,%.3f,%.2f\n' % r)
         f.write('"TOTAL (conv kernels)",all,,%.1f,%.2f,%.1f,%.3f,\n' % (totf, ts, totf / ts, totf / ts / PEAK))
