@@ -132,8 +132,8 @@ def check_optimizer_calls(cfg, calls, iteration, lrs):
     1e-5) (train.py:171-176) moves them from the same parameters, moments, step counts and gradients — 1e-6 of the update."""
     want = (["idis", "vdis", "gdis"] if iteration % cfg.num_gen_update == 0 else []) + (["ggen", "cgen", "ggen"] if iteration % cfg.num_dis_update == 0 else [])
     assert [c[0] for c in calls] == want, ([c[0] for c in calls], want)
-    worst = 0.0
-    for name, pre, post in calls:
+    worst, where = 0.0, None
+    for ci, (name, pre, post) in enumerate(calls):
         ps = [torch.nn.Parameter(t.clone()) for t, _, _ in pre]
         ref = torch.optim.Adam(ps, lr=lrs[name], betas=(0.5, 0.999), eps=1e-8, weight_decay=cfg.decay[name] if getattr(cfg, "decay", None) else 1e-5)
         for q, (_, g, st) in zip(ps, pre):
@@ -147,6 +147,8 @@ def check_optimizer_calls(cfg, calls, iteration, lrs):
                 continue
             d_ref, d_hip = (q.detach() - t0).double(), (t1 - t0).double()
             assert float(d_ref.norm()) > 0
-            worst = max(worst, float((d_hip - d_ref).norm() / d_ref.norm()))
-    assert worst <= 1e-5, worst
+            e = float((d_hip - d_ref).norm() / d_ref.norm())
+            if e > worst:
+                worst, where = e, (ci, name, tuple(t0.shape), float(g.abs().max()), float(d_ref.norm()))
+    assert worst <= 1e-5, (worst, where)
     return worst
