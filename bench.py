@@ -252,6 +252,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()     # rank 0 runs the dominant-kernel probe and prints before anyone tears the communicator down
         dist.destroy_process_group()
 
 
