@@ -246,3 +246,30 @@ def test_fullwidth_training_step(dev, fixture):
     assert r.pos == len(so.rng.log)
     if os.environ.get("DCV_REPORT_DIR"):
         open(os.path.join(os.environ["DCV_REPORT_DIR"], fixture + ".step.txt"), "w").write(f"worst 1 - cos(update, reference update) {worst:.3e}\n")
+
+
+def test_iteration_is_bitwise_reproducible(dev):
+    """Every reduction in the library has a fixed order (slab sums, per-tile BatchNorm partials, fp64 combines; no float atomics), so two
+    runs of the same full-width iteration from the same seeds give bit-identical parameters and losses — what makes a data-parallel
+    replica mismatch debuggable."""
+    from dcvgan_amd import trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    cfg = CONFIGS["isogd-depth"].scaled(batchsize=6)
+    g = torch.Generator().manual_seed(3)
+    xc = (torch.rand(6, 3, 16, 64, 64, generator=g) * 2 - 1).to(dev); xg = (torch.rand(6, 1, 16, 64, 64, generator=g) * 2 - 1).to(dev)
+
+    def run():
+        torch.manual_seed(11)
+        models = trainer.build_models(cfg, dev)
+        r = PhiloxRng(5)
+        for m in models.values():
+            m._rng = r
+        runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
+        losses = [runner.step(xc, xg, 2 + i) for i in range(2)]
+        return losses, torch.cat([v.detach().float().reshape(-1) for m in models.values() for v in m.state_dict().values()]).cpu()
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert l1 == l2
+    assert torch.equal(p1, p2)
