@@ -15,7 +15,7 @@ from torch.autograd import Function
 from . import native as N
 from .native import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvGeom, check, dims5, lib, ptr, stream_ptr
 
-__all__ = ["conv", "bn_act", "act", "noise_add", "cat_channels", "temporal_diff", "gan_loss", "gru_sequence",
+__all__ = ["invalidate_packed_weights", "conv", "bn_act", "act", "noise_add", "cat_channels", "temporal_diff", "gan_loss", "gru_sequence",
            "normal", "dropout2d_mask", "conv_geom", "ACT_NONE", "ACT_LEAKY", "ACT_TANH"]
 
 
@@ -135,6 +135,17 @@ def _pack_of(w):
     if pc is None:
         pc = w._dcv_pack = _PackCache()
     return pc
+
+
+def invalidate_packed_weights(obj) -> None:
+    """Forget the cached packed copies of a weight tensor / of every parameter of a module.  Needed only after an in-place
+    edit that autograd cannot see (`p.data.normal_()`, a raw-pointer write): such edits do not bump `p._version`, the
+    stamp the caches are validated with.  load_state_dict / copy_ / in-place ops on the parameter itself / torch and HIP
+    optimiser steps / util.init_weights all bump it and need nothing."""
+    ts = obj.parameters() if isinstance(obj, torch.nn.Module) else [obj]
+    for t in ts:
+        if getattr(t, "_dcv_pack", None) is not None:
+            t._dcv_pack = None
 
 
 class _Conv(Function):

@@ -20,6 +20,8 @@ def init_weights(layer) -> None:
     kind = type(layer)
     if kind is nn.Conv2d or kind is nn.ConvTranspose2d:
         nn.init.normal_(layer.weight.data, 0.0, 0.02)
+        # `.data` writes bypass autograd's version counter, which the packed-weight caches are keyed on (ops._PackCache)
+        torch.autograd.graph.increment_version(layer.weight)
     elif kind is nn.BatchNorm2d:
         nn.init.normal_(layer.weight.data, 1.0, 0.02)
         nn.init.constant_(layer.bias.data, 0.0)

@@ -146,6 +146,28 @@ def test_conv_backward_data_accumulates_into_a_slice(dev, case):
         assert rel(wide2_d, want2) < 1e-5 and torch.equal(wide2_d[:, :5].cpu(), wide[:, :5])
 
 
+def test_packed_weight_cache_follows_the_weights(dev):
+    """The K-major packed copy is cached per (weight tensor, autograd version): in-place updates that bump the version
+    (optimiser steps, copy_, load_state_dict) are seen; an edit through `.data` is not, until the cache is invalidated."""
+    from dcvgan_amd import ops, util
+    g = torch.Generator().manual_seed(9)
+    conv = torch.nn.Conv2d(16, 64, 4, 2, 1, bias=False).to(dev)
+    x = torch.randn(3, 16, 32, 32, generator=g).to(dev)
+    geom = ops.conv_geom(conv.weight, (2, 2), (1, 1), False)
+    with torch.no_grad():
+        y0 = ops.conv(x, conv.weight, geom).clone()
+        conv.weight.mul_(2.0)                                   # bumps the version
+        assert rel(ops.conv(x, conv.weight, geom), 2 * y0) < 1e-6
+        conv.weight.data.mul_(0.5)                              # does not
+        ops.invalidate_packed_weights(conv)
+        assert rel(ops.conv(x, conv.weight, geom), y0) < 1e-6
+        w_before = conv.weight.detach().clone()
+        conv.apply(util.init_weights)                           # `.data.normal_` + an explicit version bump
+        y2 = ops.conv(x, conv.weight, geom)
+        assert not torch.equal(conv.weight, w_before)
+        assert rel(y2, F.conv2d(x.cpu(), conv.weight.detach().cpu(), None, 2, 1)) < 1e-5
+
+
 def test_conv_fused_act(dev):
     from dcvgan_amd import ops
     g = torch.Generator().manual_seed(3)
