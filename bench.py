@@ -89,10 +89,11 @@ def committed_traffic(batch):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")))
         if int(t.get("batch", -1)) == int(batch):
-            return {"bytes_per_launch": t["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "source": "profiles/r02_dominant_kernel_pmc.json"}
+            return t["hbm_bytes_per_launch"], {"algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "unit": "bytes per launch",
+                                               "source": "profiles/r02_dominant_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)"}
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def host_threads():
@@ -230,6 +231,7 @@ def main():
         step_tflops = f_step * (B / per_step) / 1e12        # per GPU
         probe = dominant_kernel_probe(models, cfg, dev)
         gb_step = ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION * B
+        traffic, traffic_detail = committed_traffic(B) if a.precision == "fp32" else (None, None)
         gating = "" if cfg.num_gen_update == 1 else f", D update every {cfg.num_gen_update} iterations (FLOPs averaged over the cycle)"
         line = {
             "metric": "videos/sec per G+D step, 16x64x64 RGB+depth" if cfg.channel == 1 else "videos/sec per G+D step, 16x64x64 RGB+flow",
@@ -240,7 +242,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "clip": f"16x64x64 RGB + {cfg.channel}-channel {cfg.geometric_info}",
                        "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup)},
             "roofline": {"bound": "mfma", "achieved": probe["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": probe["tflops"] / peak, "traffic": committed_traffic(B) if a.precision == "fp32" else None,
+                         "frac": probe["tflops"] / peak, "traffic": traffic, "traffic_detail": traffic_detail,
                          "kernel": probe,
                          "step": {"achieved": step_tflops, "frac": step_tflops / peak, "flops_per_video_step": f_step},
                          "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,
