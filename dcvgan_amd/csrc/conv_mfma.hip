@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int 
 #pragma unroll
         for (int c = 0; c < NOC; ++c) acc[p][c] = 0.f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll 2
     for (int rc = wave; rc < RC; rc += 4) {
         const f32x4* __restrict__ wrow = reinterpret_cast<const f32x4*>(a.wp) + (int64_t)rc * T;   // wave-uniform
 #pragma unroll
@@ -1882,9 +1883,10 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     else DCV_LAUNCH_DMA(1, 2, 1, 4)
 #undef DCV_LAUNCH_DMA
 #undef DCV_LAUNCH_DMA1
-    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s%s> (%d x %d tile, %d class%s in one launch%s)",
+    DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s, %s> (%d x %d tile, %d class%s in one launch%s%s)",
                     tc.bn == 128 ? (tc.bm == 64 ? "2, 1, 2, 2" : "2, 2, 2, 2") : tc.bn == 64 ? (tc.bm == 128 ? "2, 1, 1, 4" : "2, 2, 1, 4") : "1, 2, 1, 4",
-                    ds ? "true" : "false", pt ? "true" : "false", bfm ? ", bf16" : "", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "");
+                    ds ? "true" : "false", pt ? "true" : "false", bfm ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "",
+                    bfm ? ", bf16 products" : "");
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
@@ -2634,8 +2636,11 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
             a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
         }
     }
-    DCV_NOTE_KERNEL("%s%s (%d x %d tile, %d slabs)", dma && a.log2nd >= 0 ? (tc.bd == 128 ? "wgrad_dma_kernel<2>" : "wgrad_dma_kernel<1>") : "wgrad_gemm_kernel",
-                    dma && a.log2nd >= 0 && g_precision.load(std::memory_order_relaxed) == 1 ? " bf16" : "", tc.bd, tc.bj, S2);
+    {
+        const bool wbf = g_precision.load(std::memory_order_relaxed) == 1;
+        if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf ? "true" : "false", tc.bd, tc.bj, S2, wbf ? ", bf16 products" : "");
+        else DCV_NOTE_KERNEL("wgrad_gemm_kernel (%d x %d tile, %d slabs)", tc.bd, tc.bj, S2);
+    }
     if (dma && a.log2nd >= 0 && g_precision.load(std::memory_order_relaxed) == 1) {
         if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((wgrad_dma_kernel<1, true>), dim3(tiles, S2), dim3(256), 0, stream, a);

@@ -8,8 +8,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by a cgroup CPU quota (the GPU boxes show 256 cores behind a
+    16-CPU quota: torch's default of one thread per visible core makes the oracle's CPU passes several times slower there)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(min(32, _usable_cpus()))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -43,7 +43,6 @@ def rel(a, b):
 def dev():
     from dcvgan_amd import native
     native.lib()
-    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     return torch.device("cuda:0")
 
 
