@@ -1125,7 +1125,6 @@ __global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int 
 #pragma unroll
         for (int c = 0; c < NOC; ++c) acc[p][c] = 0.f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll 2
     for (int rc = wave; rc < RC; rc += 4) {
         const f32x4* __restrict__ wrow = reinterpret_cast<const f32x4*>(a.wp) + (int64_t)rc * T;   // wave-uniform
 #pragma unroll
