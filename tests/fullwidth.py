@@ -67,6 +67,53 @@ def oracle_gen_pass(cfg, models, seed_run, t, dtype=torch.float32, kinks=None):
     return dict(xg=xg.detach(), xc=xc.detach(), yi=yi.detach(), yv=yv.detach(), yg=yg.detach(), loss=loss.detach(), grads=grads, log=rng.log, st=st)
 
 
+def oracle_dis_pass(cfg, models, seed_run, t, xc_real, xg_real, dtype=torch.float32, kinks=None):
+    """The D phase of trainer.py:285-319: D(real), fakes WITH their graph (not detached), D(fake), the three discriminator losses,
+    one backward — gradients of all five models (the generators' are the 'dead' ones the reference computes and discards)."""
+    if kinks is not None:
+        with O.KinkTape(kinks) as tape:
+            r = oracle_dis_pass(cfg, models, seed_run, t, xc_real, xg_real, dtype)
+        assert tape.pos == len(kinks), (tape.pos, len(kinks))
+        r["kink_mismatch"] = tape.mismatch
+        return r
+    st = states_of(models, dtype)
+    torch.manual_seed(seed_run)
+    so = O.StepOracle(cfg, st, O.TorchRng() if dtype == torch.float32 else Rng64())
+    xc_r, xg_r = xc_real.to(dtype), xg_real.to(dtype)
+    yr = so.dis_all(xg_r, xc_r, t)
+    xg_f, xc_f = so.fakes()
+    yf = so.dis_all(xg_f, xc_f, t)
+    losses = [O.dis_loss(cfg.loss, a, b) for a, b in zip(yr, yf)]
+    (losses[0] + losses[1] + losses[2]).backward()
+    grads = {(n, k): (None if p.grad is None else p.grad.detach()) for n in MODELS for k, p in st[n].items() if p.requires_grad}
+    return dict(losses=[l.detach() for l in losses], grads=grads, log=so.rng.log)
+
+
+def hip_dis_pass(cfg, models, log, t, xc_real, xg_real, dev):
+    from dcvgan_amd import layers, trainer
+    from dcvgan_amd.rng import InjectedRng
+    to_device(models, dev)
+    for m in models.values():
+        m.zero_grad()
+        m.train()
+    r = InjectedRng(log)
+    for m in models.values():
+        m._rng = r
+    layers.KINK_TAP = kinks = []
+    xc_r, xg_r = xc_real.to(dev), xg_real.to(dev)
+    B = cfg.batchsize
+    y_real = (models["idis"](xg_r[:, :, t], xc_r[:, :, t]), models["vdis"](xg_r, xc_r), models["gdis"](xg_r, xc_r))
+    xg = models["ggen"].sample_videos(B); xc = models["cgen"].forward_videos(xg)
+    y_fake = (models["idis"](xg[:, :, t], xc[:, :, t]), models["vdis"](xg, xc), models["gdis"](xg, xc))
+    layers.KINK_TAP = None
+    L = trainer.build_loss(cfg)
+    losses = [L.compute_dis_loss(a, b) for a, b in zip(y_real, y_fake)]
+    (losses[0] + losses[1] + losses[2]).backward()
+    assert r.pos == len(log)
+    grads = {(n, k): (None if p.grad is None else p.grad.detach().cpu()) for n in MODELS for k, p in models[n].named_parameters()}
+    return dict(losses=[l.detach().cpu() for l in losses], grads=grads, kinks=kinks)
+
+
 def to_device(models, dev):
     for m in models.values():
         m.to(dev)

@@ -102,6 +102,31 @@ def test_fullwidth_b2_against_reference_and_fp64(dev, fixture):
         assert G.relerr(FW.gsub(gh), fx[f"gradsub/{n}/{k}"]) < 3e-2, (n, k)
 
 
+@pytest.mark.parametrize("name,B", [("isogd-depth", 2), ("surreal-depth1", 2), ("isogd-flow", 2), ("isogd-depth", 8)])
+def test_fullwidth_discriminator_phase(dev, name, B):
+    """The OTHER backward of an iteration (trainer.py:285-319): the discriminator losses on a real and a fake batch, backpropagated
+    through the discriminators (no data gradient into the real inputs, parameter gradients accumulated over both batches) and — the
+    fakes are not detached — on through cgen and ggen.  BCE-with-logits for isogd-depth, hinge for the other two.  Same two statements
+    as the generator-phase tests: arithmetic with the HIP pass's activation pattern replayed in fp64, and the pattern itself."""
+    from dcvgan_amd import trainer
+    from dcvgan_amd.configs import CONFIGS
+    cfg = CONFIGS[name].scaled(batchsize=B)
+    torch.manual_seed(777)
+    models = trainer.build_models(cfg, torch.device("cpu"))
+    g = torch.Generator().manual_seed(5)
+    lo, hi = (-0.5, 0.5) if cfg.channel == 2 else (-1.0, 1.0)
+    xc_real = torch.rand(B, 3, 16, 64, 64, generator=g) * 2 - 1
+    xg_real = torch.rand(B, cfg.channel, 16, 64, 64, generator=g) * (hi - lo) + lo
+    r32 = FW.oracle_dis_pass(cfg, models, 99, 4, xc_real, xg_real)
+    r64 = FW.oracle_dis_pass(cfg, models, 99, 4, xc_real, xg_real, torch.float64)
+    hip = FW.hip_dis_pass(cfg, models, r32["log"], 4, xc_real, xg_real, dev)
+    r64k = FW.oracle_dis_pass(cfg, models, 99, 4, xc_real, xg_real, torch.float64, kinks=hip["kinks"])
+    for a, b in zip(hip["losses"], r64["losses"]):
+        assert abs(a.item() - b.item()) < TOL * abs(b.item())
+    rows = _check_gradients(f"{name}_b{B}_dphase", hip, r32, r64, r64k)
+    assert len(rows) >= 80          # every parameter tensor of all five models received a gradient
+
+
 @pytest.mark.parametrize("name", ["isogd-depth", "surreal-depth1", "isogd-flow"])
 def test_fullwidth_b16_against_the_oracle(dev, name):
     """B = 16: large enough that every big-problem kernel variant is taken (row-reuse thin kernels, patch staging,
