@@ -2715,6 +2715,28 @@ int dcv_get_precision(void) { return g_precision.load(); }
 int dcv_version(void) { return 1; }
 uint64_t dcv_launch_count(void) { return g_launches.load(); }
 
+// A transposed convolution of a 1x1(x1) input with stride 1 and no padding (the latent layer, generator.py:61:
+// ConvTranspose2d(dim_z, 8 ngf, 4, 1, 0)) is a plain matrix product y[n, (co, kd, kh, kw)] = sum_ci x[n, ci] w[ci, (co, kd, kh, kw)]:
+// as a k x k scatter it would walk k^3 taps of which all but one are padding for every output position.  When y is
+// contiguous per sample it is re-described as a 1x1 transposed convolution with cout * taps output channels (weights and
+// gradients are the same memory either way).
+static bool latent_form(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, dcv_conv_geom* g2, dcv_dims5* y2) {
+    if (!g || !x || !y || !g->transposed) return false;
+    const int T = g->kd * g->kh * g->kw;
+    if (T <= 1 || x->d != 1 || x->h != 1 || x->w != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1 || g->pd || g->ph || g->pw) return false;
+    if (y->d != g->kd || y->h != g->kh || y->w != g->kw || y->c != g->cout || (int64_t)g->cout * T >= (1ll << 30)) return false;
+    // (c, d, h, w) of y contiguous (stride fields of size-1 dims are normalised to 0 by the caller)
+    const int64_t sw = 1, sh = y->w, sd = (int64_t)y->h * y->w, sc = (int64_t)y->d * y->h * y->w;
+    if ((y->w > 1 && y->sw != sw) || (y->h > 1 && y->sh != sh) || (y->d > 1 && y->sd != sd) || (y->c > 1 && y->sc != sc)) return false;
+    *g2 = *g;
+    g2->kd = g2->kh = g2->kw = 1;
+    g2->cout = g->cout * T;
+    *y2 = *y;
+    y2->c = g->cout * T; y2->d = y2->h = y2->w = 1;
+    y2->sc = 1; y2->sd = y2->sh = y2->sw = 0;
+    return true;
+}
+
 // which: 0 forward, 1 backward-data, 2 backward-weight
 static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, const dcv_dims5* xd, const float* w,
                          float* out, const dcv_dims5* yd, int act, float slope, int accumulate,
@@ -2722,6 +2744,15 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
                          float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr,
                          const dcv_wpack* pack = nullptr, size_t* pack_need = nullptr, const float* gate = nullptr, float gate_slope = 0.f) {
     // xd = module input dims, yd = module output dims, always.
+    {
+        dcv_conv_geom g2;
+        dcv_dims5 y2;
+        if (!gate && latent_form(g, xd, yd, &g2, &y2)) {
+            if (stat_parts) *stat_parts = 0;       // per-(channel, tap) columns are not BatchNorm channels: the BN op runs its own statistics pass
+            if (stat_need) { *stat_need = 0; return DCV_OK; }
+            return conv_dispatch(which, &g2, a_, xd, w, out, &y2, act, slope, accumulate, ws, ws_bytes, stream, need_only, nullptr, 0, nullptr, nullptr, pack, pack_need);
+        }
+    }
     int rc = check_geom(g, xd, yd, "conv");
     if (rc != DCV_OK) return rc;
     const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
@@ -2786,6 +2817,9 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
 size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
     size_t need = 0;
     if (which == 2) {
+        dcv_conv_geom g2;
+        dcv_dims5 y2;
+        if (latent_form(g, x, y, &g2, &y2)) return dcv_conv_workspace_bytes(&g2, x, &y2, 2);
         if (check_geom(g, x, y, "conv_ws") != DCV_OK) return 0;
         const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
         const dcv_dims5& D = g->transposed ? *x : *y;
@@ -2840,6 +2874,11 @@ int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const 
 
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd,
                              float* dw, void* ws, size_t ws_bytes, void* stream) {
+    {
+        dcv_conv_geom g2;
+        dcv_dims5 y2;
+        if (latent_form(g, xd, dyd, &g2, &y2)) return dcv_conv_backward_weight(&g2, x, xd, dy, &y2, dw, ws, ws_bytes, stream);
+    }
     int rc = check_geom(g, xd, dyd, "conv_bwd_weight");
     if (rc != DCV_OK) return rc;
     if (!x || !dy || !dw || !ws) return fail(DCV_EINVAL, "conv_bwd_weight: null pointer");

@@ -176,7 +176,7 @@ def recording_optimizers(cfg, models):
 def check_optimizer_calls(cfg, calls, iteration, lrs):
     """(1) the schedule of trainer.py:318-322,355-359: idis, vdis, gdis once when the D update is due, then ggen, cgen,
     ggen; (2) every call moved its parameters EXACTLY as torch.optim.Adam(betas=(0.5, 0.999), eps 1e-8, weight_decay
-    1e-5) (train.py:171-176) moves them from the same parameters, moments, step counts and gradients — 1e-6 of the update."""
+    1e-5) (train.py:171-176) moves them from the same parameters, moments, step counts and gradients — to 1e-3 of the update, see below."""
     want = (["idis", "vdis", "gdis"] if iteration % cfg.num_gen_update == 0 else []) + (["ggen", "cgen", "ggen"] if iteration % cfg.num_dis_update == 0 else [])
     assert [c[0] for c in calls] == want, ([c[0] for c in calls], want)
     worst, where = 0.0, None
@@ -197,5 +197,9 @@ def check_optimizer_calls(cfg, calls, iteration, lrs):
             e = float((d_hip - d_ref).norm() / d_ref.norm())
             if e > worst:
                 worst, where = e, (ci, name, tuple(t0.shape), float(g.abs().max()), float(d_ref.norm()))
-    assert worst <= 1e-5, (worst, where)
+    # 1e-3 of the update, not tighter: g + weight_decay * p is one fused multiply-add in torch's vectorised CPU kernel and a multiply
+    # and an add here, and where a gradient element nearly cancels weight_decay * p (|g'| ~ eps) the ulp of difference moves that
+    # element's m / (sqrt(v) + eps) by up to ~1e-3 (observed 7e-5 of a 16-element tensor's update).  A missing step, a wrong learning
+    # rate, beta, weight decay or bias correction is off by per cents; elementwise agreement on generic data is tests/test_adam_gpu.py's 1e-6.
+    assert worst <= 1e-3, (worst, where)
     return worst
