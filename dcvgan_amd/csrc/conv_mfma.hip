@@ -1264,6 +1264,133 @@ __global__ __launch_bounds__(256) void widen_rows_kernel(const GatherArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------- //
+// thin_quad_kernel: OC <= 4 outputs of a 4x4, stride-2, pad-1 SCATTER-form op (conv data gradient / transposed-conv forward)
+// on 32-wide gathered rows -> 64-wide output rows, 1 or 4 depth taps (stride 1, no depth padding): the geometry generator's
+// depth / flow head and the data gradients of the 3-D discriminators' stems.  thin_rows_kernel runs these as four stride-parity
+// classes, each of which re-reads the same gathered rows (20 row loads per 64 multiply-adds and channel); here a lane owns the
+// 2x2 output quads of one gathered column for two quad rows: the 4 gathered rows it needs are loaded once per (channel, depth
+// tap), their left / right neighbours come from DPP wave shifts, and all 16 taps are applied — 4 row loads per 32 multiply-adds,
+// and the two outputs of a quad row are stored as one 8-byte pair (whole 256-byte row segments per half-wave).
+// Block = 4 waves x (2 half-waves x 2 quad rows) = 8 output rows of one (n, output depth) plane; the waves split the channels.
+// --------------------------------------------------------------------------- //
+struct QuadArgs {
+    const float* s;
+    float* y;
+    const float* w;
+    int32_t N, RC, OC, SD, SH, OD, pad0, pad1;
+    int64_t s_sn, s_sc, s_sd, s_sh;
+    int64_t y_sn, y_sc, y_sd, y_sh;
+    int64_t w_o, w_r;      // weight element (output channel c, gathered channel rc, kd, kh, kw) at c * w_o + rc * w_r + (kd * 4 + kh) * 4 + kw
+    int32_t act, accumulate;
+    float slope, pad2;
+};
+
+template <int NOC, int ND>
+__global__ __launch_bounds__(256) void thin_quad_kernel(const QuadArgs a) {
+    __shared__ float red[3][8 * NOC][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, hw = lane >> 5;
+    const uint32_t qb = (uint32_t)a.SH >> 2;                       // blocks per plane: 4 quad rows each
+    const uint32_t plane = blockIdx.x / qb;
+    const int r0 = (int)(blockIdx.x - plane * qb) * 4 + 2 * hw;    // this half-wave's first quad row (= gathered row)
+    const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
+    // the 4 gathered rows r0 - 1 .. r0 + 2: element offsets inside a (channel, depth) plane, or -1 outside the tensor
+    int roff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 - 1 + i;
+        roff[i] = (unsigned)rr < (unsigned)a.SH ? rr * (int)a.s_sh + col : -1;
+    }
+    float acc[2][2][2][NOC];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < NOC; ++c) acc[q][h][b][c] = 0.f;
+    const float* __restrict__ sn = a.s + (int64_t)n * a.s_sn;
+#pragma unroll(ND == 1 ? 4 : 1)
+    for (int rc = wave; rc < a.RC; rc += 4) {
+        // all row loads of this channel first (4 per depth tap), so that they are in flight together
+        float ctr[ND][4];
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd) {
+            const int sd = (int)od - kd;                           // produced depth = gathered depth + kd
+            const bool in = (unsigned)sd < (unsigned)a.SD;         // block-uniform
+            const float* __restrict__ pl = sn + (int64_t)rc * a.s_sc + (int64_t)(in ? sd : 0) * a.s_sd;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ctr[kd][i] = (in && roff[i] >= 0) ? pl[roff[i]] : 0.f;
+        }
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd) {
+            float g[4][3];                                         // [row][left, centre, right]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = ctr[kd][i];
+                g[i][1] = v;
+                float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));   // wave_shr:1 -> column - 1
+                float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));   // wave_shl:1 -> column + 1
+                g[i][0] = col == 0 ? 0.f : l;                      // the seam between the wave's two 32-wide rows is padding
+                g[i][2] = col == 31 ? 0.f : r;
+            }
+#pragma unroll
+            for (int c = 0; c < NOC; ++c) {
+                if (c >= a.OC) continue;
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4* __restrict__ wq = reinterpret_cast<const f32x4*>(a.w + (int64_t)c * a.w_o + (int64_t)rc * a.w_r + kd * 16);   // wave-uniform: w[kh][0..3]
+                const f32x4 w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float (&top)[3] = g[q], (&mid)[3] = g[q + 1], (&bot)[3] = g[q + 2];
+                    // output row 2r     : gathered row r (kh = 1) and r - 1 (kh = 3);  output row 2r + 1: row r + 1 (kh = 0) and r (kh = 2)
+                    // output col 2c     : gathered col c (kw = 1) and c - 1 (kw = 3);  output col 2c + 1: col c + 1 (kw = 0) and c (kw = 2)
+                    acc[q][0][0][c] += mid[1] * w1[1] + mid[0] * w1[3] + top[1] * w3[1] + top[0] * w3[3];
+                    acc[q][0][1][c] += mid[2] * w1[0] + mid[1] * w1[2] + top[2] * w3[0] + top[1] * w3[2];
+                    acc[q][1][0][c] += bot[1] * w0[1] + bot[0] * w0[3] + mid[1] * w2[1] + mid[0] * w2[3];
+                    acc[q][1][1][c] += bot[2] * w0[0] + bot[1] * w0[2] + mid[2] * w2[0] + mid[1] * w2[2];
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < NOC; ++c) red[wave - 1][((q * 2 + h) * 2 + b) * NOC + c][lane] = acc[q][h][b][c];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int OC = a.OC, act = a.act, accumulate = a.accumulate;
+    const float slope = a.slope;
+    float* __restrict__ yb = a.y + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + 2 * col;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c = 0; c < NOC; ++c) {
+                if (c >= OC) continue;
+                float v[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int e = ((q * 2 + h) * 2 + b) * NOC + c;
+                    v[b] = acc[q][h][b][c] + ((red[0][e][lane] + red[1][e][lane]) + red[2][e][lane]);
+                }
+                float* dst = yb + (int64_t)(2 * (r0 + q) + h) * a.y_sh + (int64_t)c * a.y_sc;
+                if (accumulate) { v[0] += dst[0]; v[1] += dst[1]; }
+                dst[0] = apply_act(v[0], act, slope);
+                dst[1] = apply_act(v[1], act, slope);
+            }
+}
+
 template <int T>
 static bool launch_thin_struct(const GatherArgs& a, int OC, int RC, int rc_per_split, dim3 grid, hipStream_t s) {
     switch (OC) {
@@ -1756,12 +1883,12 @@ static std::map<std::string, DevTable> g_tables;   // keys start with the device
 
 // A/B switches for tools/ (variant off when the variable is set); read once, not per call
 struct Toggles {
-    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64;
+    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64, no_quad;
     int half_m;
     Toggles() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
-        no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64");
+        no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD");
         half_m = getenv("DCV_HALF_M") ? atoi(getenv("DCV_HALF_M")) : -1;
     }
 };
@@ -2737,6 +2864,42 @@ static bool latent_form(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
     return true;
 }
 
+// OC <= 4 scatter-form ops of the 4x4 / stride-2 / pad-1 family on 32 -> 64 wide rows: thin_quad_kernel (returns false when the
+// geometry is another one and the generic class-by-class path has to run)
+static bool try_thin_quad(const float* src, const dcv_dims5& sd_, float* dst, const dcv_dims5& dd, const float* w, const int k[3], const int s[3], const int p[3],
+                          int act, float slope, int accumulate, hipStream_t stream) {
+    if (toggles().no_quad) return false;
+    const int OC = dd.c, RC = sd_.c;
+    if (OC > 4 || k[1] != 4 || k[2] != 4 || s[1] != 2 || s[2] != 2 || p[1] != 1 || p[2] != 1 || s[0] != 1 || p[0] != 0 || (k[0] != 1 && k[0] != 4)) return false;
+    if (sd_.w != 32 || dd.w != 64 || dd.h != 2 * sd_.h || sd_.h % 4 != 0 || sd_.sw != 1 || dd.sw != 1) return false;
+    if (dd.d != sd_.d + k[0] - 1) return false;
+    if ((int64_t)dd.n * dd.d * (sd_.h / 4) >= (1ll << 31) || sd_.sh * (int64_t)sd_.h >= (1ll << 30)) return false;
+    QuadArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s = src; a.y = dst; a.w = w;
+    a.N = dd.n; a.RC = RC; a.OC = OC; a.SD = sd_.d; a.SH = sd_.h; a.OD = dd.d;
+    a.s_sn = sd_.sn; a.s_sc = sd_.sc; a.s_sd = sd_.sd; a.s_sh = sd_.sh;
+    a.y_sn = dd.sn; a.y_sc = dd.sc; a.y_sd = dd.sd; a.y_sh = dd.sh;
+    const int T = k[0] * 16;
+    a.w_o = T; a.w_r = (int64_t)OC * T;
+    a.act = act; a.slope = slope; a.accumulate = accumulate;
+    const dim3 grid((unsigned)((int64_t)dd.n * dd.d * (sd_.h / 4)));
+#define DCV_QUAD(NOC_)                                                                                          \
+    {                                                                                                           \
+        if (k[0] == 1) hipLaunchKernelGGL((thin_quad_kernel<NOC_, 1>), grid, dim3(256), 0, stream, a);          \
+        else hipLaunchKernelGGL((thin_quad_kernel<NOC_, 4>), grid, dim3(256), 0, stream, a);                    \
+    }
+    switch (OC) {
+        case 1: DCV_QUAD(1) break;
+        case 2: DCV_QUAD(2) break;
+        case 3: DCV_QUAD(3) break;
+        default: DCV_QUAD(4) break;
+    }
+#undef DCV_QUAD
+    DCV_NOTE_KERNEL("thin_quad_kernel<%d, %d>", OC, k[0]);
+    return true;
+}
+
 // which: 0 forward, 1 backward-data, 2 backward-weight
 static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, const dcv_dims5* xd, const float* w,
                          float* out, const dcv_dims5* yd, int act, float slope, int accumulate,
@@ -2807,6 +2970,11 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
             return DCV_OK;
         }
         if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
+        if (!direct && !stat && !gate && try_thin_quad(a_, src, out, dst, w, k, s, p, act, slope, accumulate, st)) {
+            if (stat_parts) *stat_parts = 0;
+            DCV_LAUNCH_CHECK();
+            return DCV_OK;
+        }
         return run_gather(a_, src, out, dst, w, RC, OC, ws_o, ws_r, k[1], k[2], cls, act, slope, accumulate, ws, ws_bytes, st,
                           which == 0 ? (g->transposed ? "convT_fwd" : "conv_fwd") : (g->transposed ? "convT_bwd_data" : "conv_bwd_data"),
                           stat, stat_bytes, stat_parts, pack, gate, gate_slope);
