@@ -1842,6 +1842,141 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
             }
 }
 
+// --------------------------------------------------------------------------- //
+// Thin weight gradient of the colour generator's stem (1 or 2 gathered channels -> 64, 3x3, 64-wide rows).  As a GEMM the
+// reduction runs over positions and one side is only GC x 9 = 9 / 18 wide: the MFMA tile is mostly padding, the im2col staging
+// of the thin operand dominates and the 1.2 GB dense gradient streams at a quarter of the HBM rate.  Here a lane owns one column
+// of the dense tensor: the 3x3 neighbourhood of the thin operand lives in registers (rows loaded once, horizontal neighbours
+// from DPP wave shifts), each dense value is loaded once (coalesced rows) and multiplied into DCW x GC x 9 per-lane
+// accumulators; a wave walks `pps` images, then reduces its accumulators over the 64 lanes (DPP) and writes one slab row, which
+// wgrad_reduce_kernel sums in a fixed order.  (Measured and dropped: the same scheme for 3 gathered channels - the RGB head,
+// 0.89 ms against 0.60 ms on the MFMA path - and for the 4x4(x4) stride-2 stems, 0.18-0.48 ms against 0.13-0.24 ms: with 27+
+// taps per dense value the MFMA tile is no longer mostly padding and the VALU form is slower.)
+// --------------------------------------------------------------------------- //
+struct ThinWgradArgs {
+    const float* d;
+    const float* g;
+    float* slab;
+    int32_t P, DC, OH, J, pps, pad;   // P images
+    int64_t d_sn, d_sc, d_sh;
+    int64_t g_sn, g_sc, g_sh;
+};
+
+__device__ __forceinline__ float wave_total(float v) {   // sum over the 64 lanes, wave-uniform
+    v = half_wave_sum(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ float dpp_prev_lane(float v) {   // lane - 1 (0 into lane 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_next_lane(float v) {   // lane + 1 (0 into lane 63)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// 3x3, stride 1, padding 1, 64-wide rows, 2-D: dw[dc][gc][kh][kw] = sum d[n, dc, r, c] * g[n, gc, r - 1 + kh, c - 1 + kw].
+// The rows of the wave's images form one stream, walked in chunks of CH rows: the loads of the next chunk (CH dense rows of DCW
+// channels, CH gathered rows of NG channels) are issued before the multiply-adds of the current one, and nothing in the loop
+// is conditional (rows past an image's edge are loaded from a clamped address and zeroed by a select), so the waits are
+// counter waits on loads issued a chunk earlier.
+template <int NG, int DCW>
+__global__ __launch_bounds__(256) void thin_wgrad3_kernel(const ThinWgradArgs a) {
+    constexpr int CNT = DCW * NG * 9, CH = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dc0 = ((int)blockIdx.x * 4 + wave) * DCW;
+    const int p0 = (int)blockIdx.y * a.pps, p1 = min(p0 + a.pps, a.P);
+    const int H = a.OH;
+    float acc[DCW][NG][3][3];
+#pragma unroll
+    for (int j = 0; j < DCW; ++j)
+#pragma unroll
+        for (int gc = 0; gc < NG; ++gc)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[j][gc][t / 3][t % 3] = 0.f;
+    const float* __restrict__ gb = a.g + lane;
+    const float* __restrict__ db = a.d + (int64_t)dc0 * a.d_sc + lane;
+    float gn[CH][NG], dn[CH][DCW];
+    // chunk (n, r0): dense rows r0 .. r0 + CH - 1 and gathered rows r0 + 1 .. r0 + CH of image n; the row after an image's last
+    // one is row 0 of the next image (it becomes the window's centre row there; as a "row below" it is masked)
+    auto load_chunk = [&](int n, int r0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            int gr = r0 + i + 1, gi = n;
+            if (gr >= H) { gr = 0; gi = min(n + 1, p1 - 1); }   // wave-uniform
+            const float* gp = gb + (int64_t)gi * a.g_sn + (int64_t)gr * a.g_sh;
+#pragma unroll
+            for (int gc = 0; gc < NG; ++gc) gn[i][gc] = gp[(int64_t)gc * a.g_sc];
+            const float* dp = db + (int64_t)n * a.d_sn + (int64_t)(r0 + i) * a.d_sh;
+#pragma unroll
+            for (int j = 0; j < DCW; ++j) dn[i][j] = dp[(int64_t)j * a.d_sc];
+        }
+    };
+    float win[3][NG][3];   // gathered rows r - 1, r, r + 1; columns c - 1, c, c + 1
+#pragma unroll
+    for (int gc = 0; gc < NG; ++gc) {
+        const float v = gb[(int64_t)p0 * a.g_sn + (int64_t)gc * a.g_sc];
+        win[0][gc][0] = win[0][gc][1] = win[0][gc][2] = 0.f;
+        win[1][gc][0] = dpp_prev_lane(v); win[1][gc][1] = v; win[1][gc][2] = dpp_next_lane(v);
+    }
+    load_chunk(p0, 0);
+    int n = p0, r0 = 0;
+    const int chunks = (p1 - p0) * (H / CH);
+    for (int ch = 0; ch < chunks; ++ch) {
+        float gq[CH][NG], dq[CH][DCW];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+#pragma unroll
+            for (int gc = 0; gc < NG; ++gc) gq[i][gc] = gn[i][gc];
+#pragma unroll
+            for (int j = 0; j < DCW; ++j) dq[i][j] = dn[i][j];
+        }
+        int n2 = n, r2 = r0 + CH;
+        if (r2 >= H) { r2 = 0; n2 = min(n + 1, p1 - 1); }
+        load_chunk(n2, r2);   // the prefetch after the last chunk re-reads valid rows and is dropped
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const bool top = r0 + i == 0, bot = r0 + i == H - 1;
+#pragma unroll
+            for (int gc = 0; gc < NG; ++gc) {
+                const float v = gq[i][gc];
+                win[2][gc][0] = dpp_prev_lane(v); win[2][gc][1] = v; win[2][gc][2] = dpp_next_lane(v);
+            }
+#pragma unroll
+            for (int gc = 0; gc < NG; ++gc)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float w0 = top ? 0.f : win[0][gc][kw], w1 = win[1][gc][kw], w2 = bot ? 0.f : win[2][gc][kw];
+#pragma unroll
+                    for (int j = 0; j < DCW; ++j) {
+                        acc[j][gc][0][kw] += dq[i][j] * w0;
+                        acc[j][gc][1][kw] += dq[i][j] * w1;
+                        acc[j][gc][2][kw] += dq[i][j] * w2;
+                    }
+                }
+#pragma unroll
+            for (int gc = 0; gc < NG; ++gc)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) { win[0][gc][kw] = win[1][gc][kw]; win[1][gc][kw] = win[2][gc][kw]; }
+        }
+        n = n2; r0 = r2;
+    }
+    // accumulator idx = (j * NG + gc) * 9 + t is element dc0 * J + idx of the slab row (J = NG * 9): lane idx % 64 keeps it
+    float out[(CNT + 63) / 64];
+#pragma unroll
+    for (int o = 0; o < (CNT + 63) / 64; ++o) out[o] = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < CNT; ++idx) {
+        const float tot = wave_total(acc[idx / (NG * 9)][idx / 9 % NG][idx % 9 / 3][idx % 3]);
+        if (lane == idx % 64) out[idx / 64] = tot;
+    }
+    float* __restrict__ row = a.slab + (int64_t)blockIdx.y * a.DC * a.J + (int64_t)dc0 * a.J;
+#pragma unroll
+    for (int o = 0; o < (CNT + 63) / 64; ++o)
+        if (o * 64 + lane < CNT) row[o * 64 + lane] = out[o];
+}
+
 // dw[dc][j] = sum_s slab[s][dc][j].  64 outputs per block; the 4 waves each sum every 4th split
 // (independent loads, 4-way unrolled) and wave 0 combines the four partial sums in a fixed order:
 // bitwise reproducible, and 16x more loads in flight than one thread walking all S splits.
@@ -1883,12 +2018,12 @@ static std::map<std::string, DevTable> g_tables;   // keys start with the device
 
 // A/B switches for tools/ (variant off when the variable is set); read once, not per call
 struct Toggles {
-    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64, no_quad;
+    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64, no_quad, no_thin_wgrad;
     int half_m;
     Toggles() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
-        no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD");
+        no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD"); no_thin_wgrad = on("DCV_NO_THIN_WGRAD");
         half_m = getenv("DCV_HALF_M") ? atoi(getenv("DCV_HALF_M")) : -1;
     }
 };
@@ -2637,6 +2772,47 @@ static void launch_wgrad(const WgradArgs& a, int gx, int gy, hipStream_t s) {
 
 // dense tensor D (dims dd, channels DC), gathered tensor G (dims gd, channels GC):
 // R[dc][gc][kd][kh][kw] = sum_{n,pos} D[n,dc,pos] * G[n,gc,pos*s - p + k]
+// Thin weight gradient (thin_wgrad3_kernel).  Returns -1 when the geometry is not its own.
+static int try_thin_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R, const int k[3], const int s[3], const int p[3],
+                          void* ws, size_t ws_bytes, hipStream_t stream, const char* tag, size_t* need_only) {
+    if (toggles().no_thin_wgrad) return -1;
+    const int DC = dd.c, GC = gd.c;
+    if (GC > 2 || dd.sw != 1 || gd.sw != 1 || dd.n != gd.n) return -1;
+    if (!(k[0] == 1 && k[1] == 3 && k[2] == 3 && s[0] == 1 && s[1] == 1 && s[2] == 1 && p[0] == 0 && p[1] == 1 && p[2] == 1 && dd.d == 1 && gd.d == 1 &&
+          dd.w == 64 && gd.w == 64 && dd.h == gd.h && dd.h % 4 == 0))
+        return -1;
+    const int dcw = GC == 1 ? 8 : 4;
+    if (DC % (4 * dcw) != 0) return -1;
+    const int groups = DC / (4 * dcw);
+    const int P = dd.n;
+    const int J = GC * 9;
+    int nslab = std::max(1, std::min(P, 2048 / groups));
+    const int pps = (P + nslab - 1) / nslab;
+    nslab = (P + pps - 1) / pps;
+    const size_t need = align_up((size_t)nslab * DC * J * sizeof(float), 256);
+    if (need_only) {
+        *need_only = need + 256;
+        return DCV_OK;
+    }
+    if (!D || !G || !R || !ws) return fail(DCV_EINVAL, "%s: null pointer", tag);
+    if (need > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, need, ws_bytes);
+    ThinWgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.d = D; a.g = G; a.slab = static_cast<float*>(ws);
+    a.P = P; a.DC = DC; a.OH = dd.h; a.J = J; a.pps = pps;
+    a.d_sn = dd.sn; a.d_sc = dd.sc; a.d_sh = dd.sh;
+    a.g_sn = gd.sn; a.g_sc = gd.sc; a.g_sh = gd.sh;
+    const dim3 grid((unsigned)groups, (unsigned)nslab);
+    if (GC == 1) hipLaunchKernelGGL((thin_wgrad3_kernel<1, 8>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((thin_wgrad3_kernel<2, 4>), grid, dim3(256), 0, stream, a);
+    DCV_NOTE_KERNEL("thin_wgrad3_kernel<%d, %d> (%d slabs)", GC, dcw, nslab);
+    DCV_LAUNCH_CHECK();
+    const int64_t tot = (int64_t)DC * J;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, nslab, DC, J, DC, J);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R,
                      const int k[3], const int s[3], const int p[3], void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
                      size_t* need_only) {
@@ -2644,6 +2820,11 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     const int T = k[0] * k[1] * k[2];
     const int64_t J64 = (int64_t)GC * T;
     if (J64 >= (1 << 30)) return fail(DCV_EUNSUPPORTED, "%s: J too large", tag);
+    size_t thin_need = 0;
+    {   // the colour generator's stem: VALU kernel
+        const int rc_ = try_thin_wgrad(D, dd, G, gd, R, k, s, p, ws, ws_bytes, stream, tag, need_only ? &thin_need : nullptr);
+        if (rc_ != -1 && !need_only) return rc_;
+    }
     const int J = (int)J64;
     const WgradTile tc = pick_wgrad_tile(DC, J);
     const int DCp = (DC + tc.bd - 1) / tc.bd * tc.bd;
@@ -2682,7 +2863,7 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     const int S2 = (int)((M64 + chunk - 1) / chunk);
     const size_t need = align_up((size_t)S2 * DCp * Jp * sizeof(float), 256);
     if (need_only) {
-        *need_only = need + 256;
+        *need_only = std::max(need + 256, thin_need);
         return DCV_OK;
     }
     if (need > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, need, ws_bytes);
