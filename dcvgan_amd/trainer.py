@@ -13,7 +13,8 @@ reference's four ``.cpu().item()`` host syncs per iteration.
 """
 from __future__ import annotations
 
-from typing import Dict
+import os
+from typing import Dict, Optional
 
 import torch
 
@@ -63,13 +64,46 @@ class StepRunner:
     losses are identical either way; only ~23 % of the step's FLOPs disappear (BASELINE.md §4,
     "minimal" column).  Default False = the reference's as-written schedule."""
 
-    def __init__(self, cfg: StepConfig, models, optimizers, loss, sync_losses: bool = False, elide_dead_backward: bool = False):
+    def __init__(self, cfg: StepConfig, models, optimizers, loss, sync_losses: bool = False, elide_dead_backward: bool = False,
+                 side_streams: Optional[bool] = None):
         self.cfg, self.models, self.opt, self.loss = cfg, models, optimizers, loss
         self.iteration = 0
         self.sync_losses = sync_losses
         self.elide_dead_backward = elide_dead_backward
+        if side_streams is None:
+            side_streams = os.environ.get("DCV_NO_SIDE_STREAMS") is None
+        self._lanes = None
+        dev = next(models["idis"].parameters()).device
+        if side_streams and dev.type == "cuda":
+            self._lanes = [torch.cuda.Stream(dev) for _ in range(3)]
         if cfg.start_in_eval:  # trainer.py:266-267: log_samples/evaluate leave the generators in eval()
             models["ggen"].eval(); models["cgen"].eval()
+
+    # The three discriminators are independent of one another (trainer.py:299-309, 347-349): each runs on its own HIP stream, so
+    # their small layers (70-frame image discriminator, the 1-channel heads, BN reductions) and the tail rounds of the large ones
+    # fill one another's idle CUs.  Autograd replays every tape entry on the stream of its forward and orders producer/consumer
+    # streams itself, and joins the leaf streams with the caller's at the end of backward(); the host order of all calls — hence
+    # every random draw and every result bit — is that of the single-stream schedule.
+    def _on_lanes(self, dis, call, join: bool = True):
+        if self._lanes is None:
+            return tuple(call(d) for d in dis)
+        main = torch.cuda.current_stream()
+        outs = []
+        for lane, d in zip(self._lanes, dis):
+            lane.wait_stream(main)          # inputs (and the optimiser's updates) were produced on the main stream
+            with torch.cuda.stream(lane):
+                outs.append(call(d))
+        if join:
+            self._adopt(outs)
+        return tuple(outs)
+
+    def _adopt(self, outs):
+        if self._lanes is None:
+            return
+        main = torch.cuda.current_stream()
+        for lane, y in zip(self._lanes, outs):
+            main.wait_stream(lane)
+            y.record_stream(main)           # allocated on the lane, read by the loss kernels on the main stream
 
     def step(self, xc_real: torch.Tensor, xg_real: torch.Tensor, t_rand: int):
         c, m, o = self.cfg, self.models, self.opt
@@ -80,11 +114,13 @@ class StepRunner:
             d.train()
         for d in (idis, vdis, gdis):
             d.zero_grad()
-        y_real = (idis(xg_real[:, :, t_rand], xc_real[:, :, t_rand]), vdis(xg_real, xc_real), gdis(xg_real, xc_real))
+        dis = (idis, vdis, gdis)
+        y_real = self._on_lanes(dis, lambda d: d(xg_real[:, :, t_rand], xc_real[:, :, t_rand]) if d is idis else d(xg_real, xc_real), join=False)
         with torch.set_grad_enabled(not self.elide_dead_backward):
-            xg_fake = ggen.sample_videos(c.batchsize)
+            xg_fake = ggen.sample_videos(c.batchsize)     # on the main stream, beside the discriminators' real-batch passes
             xc_fake = cgen.forward_videos(xg_fake)
-        y_fake = (idis(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]), vdis(xg_fake, xc_fake), gdis(xg_fake, xc_fake))
+        y_fake = self._on_lanes(dis, lambda d: d(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]) if d is idis else d(xg_fake, xc_fake))
+        self._adopt(y_real)
         loss_idis = self.loss.compute_dis_loss(y_real[0], y_fake[0])
         loss_vdis = self.loss.compute_dis_loss(y_real[1], y_fake[1])
         loss_gdis = self.loss.compute_dis_loss(y_real[2], y_fake[2])
@@ -103,7 +139,7 @@ class StepRunner:
         ggen.zero_grad(); cgen.zero_grad()
         xg_fake = ggen.sample_videos(c.batchsize)
         xc_fake = cgen.forward_videos(xg_fake)
-        y_fake = (idis(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]), vdis(xg_fake, xc_fake), gdis(xg_fake, xc_fake))
+        y_fake = self._on_lanes(dis, lambda d: d(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]) if d is idis else d(xg_fake, xc_fake))
         loss_gen = self.loss.compute_gen_loss(*y_fake)
         if self.iteration % c.num_dis_update == 0:
             loss_gen.backward()

@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B of the bench under an env toggle: tools/ab_bench.sh VAR
+# N alternating bench pairs (toggle unset / set) inside ONE gpurun call: usage  ab_bench.sh DCV_NO_XYZ [pairs] [extra bench args]
 cd "$GRAFT_REPO_ROOT" || exit 1
-for v in "" "1"; do
-  echo "=== $1=${v:-unset}"
-  if [ -n "$v" ]; then export $1=1; else unset $1; fi
-  timeout -k 10 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-minimal 2>&1 | grep '^{"metric"' | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['losses_last_step'])" || exit 1
+T=$1; P=${2:-4}; shift; shift
+for i in $(seq 1 $P); do
+a=$(timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 12 --warmup 3 "$@" 2>/dev/null | python3 -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])") || exit 1
+b=$(env $T=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --steps 12 --warmup 3 "$@" 2>/dev/null | python3 -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])") || exit 1
+echo "pair $i: new $a ms   $T=1 $b ms"
 done
