@@ -60,6 +60,12 @@ CONVS = [
     ("conv2d_4s2p1_head_big", False, 2, 8, 2, 4, 2, 1, (64, 64), 64),
     ("conv3d_4s122_stem1", False, 3, 1, 8, 4, (1, 2, 2), (0, 1, 1), (9, 64, 64), 8),
     ("conv3d_4s122_stem3", False, 3, 3, 12, 4, (1, 2, 2), (0, 1, 1), (7, 64, 64), 11),
+    # thin_quad_kernel (OC <= 4 scatter-form 4x4 / stride 2 on 32 -> 64 wide rows): 2-D stem data gradient, 2-channel head
+    ("conv2d_4s2p1_stem2", False, 2, 2, 8, 4, 2, 1, (64, 64), 4),
+    ("convT2d_4s2p1_to2", True, 2, 10, 2, 4, 2, 1, (32, 32), 6),
+    # thin_wgrad3_kernel (1 / 2 gathered channels, 3x3, 64-wide rows): the colour generator's stem
+    ("conv2d_3s1p1_stem1_wgrad", False, 2, 1, 64, 3, 1, 1, (64, 64), 5),
+    ("conv2d_3s1p1_stem2_wgrad", False, 2, 2, 96, 3, 1, 1, (64, 64), 3),
 ]
 
 
@@ -99,7 +105,7 @@ def test_conv_fwd_bwd(dev, case, strided):
 
 
 @pytest.mark.parametrize("case", [c for c in CONVS if c[0] in ("conv2d_4s2p1", "conv2d_4s2p1_wide", "conv2d_4s2p1_32_oc40", "conv2d_4s2p1_32_oc130",
-                                                                "conv2d_4s2p1_8_oc72", "conv2d_3s1p1", "conv3d_4s122_16_oc70", "convT2d_4s2p1_16_oc36")],
+                                                                "conv2d_4s2p1_8_oc72", "conv2d_3s1p1", "conv3d_4s122_16_oc70", "convT2d_4s2p1_16_oc36", "conv2d_4s2p1_stem2")],
                          ids=lambda c: c[0])
 def test_conv_backward_data_accumulates_into_a_slice(dev, case):
     """dcv_conv_backward_data(accumulate = 1): dx += conv^T(dy, w) where dx is a channel slice of a wider buffer that
@@ -369,3 +375,27 @@ def test_conv_bn_fused_statistics(dev):
         for a, b in zip(*res):
             assert rel(a.cpu(), b.cpu()) < 1e-5
     assert nfused >= 1
+
+
+def test_thin_wgrad_ragged_slabs(dev):
+    """thin_wgrad3_kernel walks `pps` images per slab; 1025 images in slabs of 2 leave a last slab of one image."""
+    import ctypes as C
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    n = 1025
+    x = torch.randn(n, 1, 64, 64, generator=g)
+    w = (torch.randn(64, 1, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, 1, 1)
+    cot = torch.randn(y_ref.shape, generator=g)
+    (gw_ref,) = torch.autograd.grad((y_ref * cot).sum(), [w])
+    x_d, dy_d = x.to(dev), cot.to(dev)
+    dw = torch.full(w.shape, float("nan"), device=dev)
+    geom = ops.conv_geom(dw, (1, 1), (1, 1), False)
+    xd, dyd = dims5(x_d), dims5(dy_d)
+    L = N.lib()
+    need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(xd), C.byref(dyd), 2)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    N.check(L.dcv_conv_backward_weight(C.byref(geom), ptr(x_d), C.byref(xd), ptr(dy_d), C.byref(dyd), ptr(dw), ptr(ws), need, stream_ptr()), "wgrad")
+    assert "thin_wgrad3_kernel<1, 8> (513 slabs)" in L.dcv_debug_last_kernel().decode()
+    assert rel(dw, gw_ref) < 1e-4

@@ -8,8 +8,13 @@ O=gpurun_out/round; mkdir -p $O; rm -rf /tmp/rp /tmp/pd_*
 timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err || { tail -3 $O/bench.err; exit 1; }
 echo "bench done"; cut -c1-200 $O/bench.json
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/rp -o r --output-format csv -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1 || { tail -3 $O/bench_under_rocprof.log; exit 1; }
-find /tmp/rp -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+find /tmp/rp -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_lanes.csv \;
 find /tmp/rp -name "*kernel_trace.csv" -exec cp {} /tmp/rp/trace.csv \;
+# the same command with the discriminators' side streams off: kernels run one at a time, so the per-kernel durations add up to the step
+# (with the lanes on, co-running kernels each report the whole overlapped interval)
+rm -rf /tmp/rs
+DCV_NO_SIDE_STREAMS=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/rs -o r --output-format csv -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_under_rocprof_serial.log 2>&1 || { tail -3 $O/bench_under_rocprof_serial.log; exit 1; }
+find /tmp/rs -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 python3 tools/dominant_from_trace.py /tmp/rp/trace.csv $O/bench_under_rocprof.log > $O/dominant_kernel_trace.json || exit 1
 echo "trace done"; cat $O/dominant_kernel_trace.json
 pd() { timeout -k 10 300 rocprofv3 --pmc $2 -d /tmp/pd_$1 -o p --output-format csv -- python3 tools/probe_dominant.py 70 10 > $O/pd_$1.log 2>&1 || { tail -3 $O/pd_$1.log; exit 1; }; }
