@@ -4,7 +4,10 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$HERE/../libdcvgan_hip.so"
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function"
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs also in the one-wave-per-SIMD kernels (wgrad_dma_kernel): with the
+# default heuristic those get AGPR accumulators, and the compiler moved all 64 of them to VGPRs and back on every tile of the K loop
+# (the conditional fold of the two-level accumulation is VALU code): 128 v_accvgpr moves per 128 MFMAs.
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p "$HERE/obj"
 pids=()
 for f in conv_mfma elementwise; do
