@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     __syncthreads();
 
 #ifdef DCV_STAMP
-    unsigned long long s_mfma = 0, s_addr = 0, s_wait = 0, s_t0 = clock64();
+    unsigned long long s_mfma = 0, s_addr = 0, s_wait = 0, s_t0 = clock64(), s_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock; constant 100 MHz clock
 #endif
     for (int it = 0; it < nit; ++it) {
         const int buf = it & 1;
@@ -1825,7 +1825,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #ifdef DCV_STAMP
     if (lane == 0 && blockIdx.x + blockIdx.y * gridDim.x < 4096) {
         unsigned long long* g = g_stamp[blockIdx.x + blockIdx.y * gridDim.x][wave];
-        g[0] = s_mfma; g[1] = s_addr; g[2] = s_wait; g[3] = 0; g[4] = clock64() - s_t0; g[5] = (unsigned long long)nit;
+        g[0] = s_mfma; g[1] = s_addr; g[2] = s_wait; g[3] = __builtin_amdgcn_s_memrealtime() - s_r0; g[4] = clock64() - s_t0; g[5] = (unsigned long long)nit;
     }
 #endif
 

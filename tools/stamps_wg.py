@@ -33,4 +33,5 @@ nb = int((b[:, 0, 5] > 0).sum())
 s = b[:nb]
 per = s[..., :3].sum(axis=(0, 1)) / s[..., 5].sum()
 print("blocks", nb, "tiles/block", s[..., 5].mean(), "cycles per tile: mfma-loop %.0f  addr+fold %.0f  wait+barrier %.0f  total %.0f ; wave lifetime %.0f" % (per[0], per[1], per[2], per.sum(), s[..., 4].mean()))
+print("shader clock while the kernel runs: %.3f GHz (s_memtime cycles per 100 MHz s_memrealtime tick, mean over waves)" % (s[..., 4] / s[..., 3] * 0.1).mean())
 print("per-wave mfma-loop cycles (block 0):", (s[0, :, 0] / s[0, :, 5]).round(), " wait:", (s[0, :, 2] / s[0, :, 5]).round())
