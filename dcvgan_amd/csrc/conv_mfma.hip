@@ -1791,14 +1791,31 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
                         DCV_WG_GROW(buf ^ 1, (q - DR) < 32 ? (q - DR) : 0)
                     }
                 }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 + TD, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TD, 0);
+            // issue order of a k-step: every MFMA is followed by a share of the step's other instructions — the wave issues in order
+            // and an MFMA occupies the matrix pipe for 64 cycles, so whatever follows ONE MFMA issues in its shadow for free, while
+            // the step's 2 + TD fragment reads and 3 row DMAs (~90 issue cycles) all behind the LAST MFMA overran its shadow by ~25
+            // cycles (8810 -> 8582 cycles per 128-MFMA tile, 8192 being the matrix pipe's own time)
             {
                 constexpr int NI = DR + 32;
-                const int left = NI - 3 * ks;
-                if (left >= 3) __builtin_amdgcn_sched_group_barrier(0x010, 3, 0);
-                else if (left == 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
-                else if (left == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                const int left = NI - 3 * ks < 0 ? 0 : (NI - 3 * ks > 3 ? 3 : NI - 3 * ks);
+                if constexpr (TD == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (left >= 2) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                    else if (left == 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (left == 3) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    if (left >= 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (left == 3) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+                    else if (left == 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
             }
         }
         }
