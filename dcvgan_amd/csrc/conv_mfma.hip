@@ -1076,6 +1076,23 @@ __global__ __launch_bounds__(256) void thin_struct_kernel(const GatherArgs a, in
         }
 }
 
+// Row-block kernels (thin_rows / thin_quad): workgroup ids go round-robin over the 8 XCDs, so with the plain plane-major numbering
+// the row blocks of one plane — which share their halo rows — land on 8 different L2s and every halo row is fetched from HBM
+// twice (the RGB head read 1.47x its input).  This map hands whole planes to an XCD: id b = 8 k + x runs (plane x + 8 (k / per),
+// row block k % per); the planes past the last full group of 8 keep the plain numbering.
+__device__ __forceinline__ void xcd_plane_map(uint32_t b, uint32_t per, uint32_t nblocks, uint32_t& plane, uint32_t& rb) {
+    const uint32_t full = nblocks / (8 * per) * (8 * per);
+    if (b < full) {
+        const uint32_t x = b & 7, k = b >> 3;
+        const uint32_t g = k / per;
+        plane = x + 8 * g;
+        rb = k - g * per;
+    } else {
+        plane = b / per;
+        rb = b - plane * per;
+    }
+}
+
 // --------------------------------------------------------------------------- //
 // thin_rows_kernel: OC <= 4, unit stride, rows one wave (64) or half a wave (32) wide, 2-3 taps per spatial
 // dim, 1 or 4 depth taps — the colour generator's RGB head (128 -> 3, 3x3 at 64x64), the data gradient of its
@@ -1095,8 +1112,9 @@ __global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = W32 ? (lane & 31) : lane;
     const uint32_t ohq = (uint32_t)a.OH / RPB;
-    const uint32_t plane = blockIdx.x / ohq;
-    const int oh0 = (int)(blockIdx.x - plane * ohq) * RPB + (W32 ? 4 * (lane >> 5) : 0);   // this lane's first output row
+    uint32_t plane, rblk;
+    xcd_plane_map(blockIdx.x, ohq, gridDim.x, plane, rblk);
+    const int oh0 = (int)rblk * RPB + (W32 ? 4 * (lane >> 5) : 0);   // this lane's first output row
     const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)n * a.x_sn), 0, 0x80000000u, 0x00020000);
     uint32_t vrow[NR];
@@ -1242,6 +1260,7 @@ __global__ __launch_bounds__(256) void widen_rows_kernel(const GatherArgs a) {
     const int OC = a.OC, OCp = a.OCp, act = a.act, accumulate = a.accumulate;
     const float slope = a.slope;
     float* __restrict__ yb = a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)lane * a.y_sw;
+    if constexpr (RC >= 3) {
     for (int oc = wave; oc < OC; oc += 4) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1260,6 +1279,38 @@ __global__ __launch_bounds__(256) void widen_rows_kernel(const GatherArgs a) {
             float x = o[p];
             if (accumulate) x += *q;
             *q = apply_act(x, act, slope);
+        }
+    }
+    return;
+    }
+    // 1 - 2 gathered channels: two output channels at a time (OCp is even): one 8-byte LDS broadcast per tap and packed multiply-adds
+    // (v_pk_fma_f32 with the input value broadcast to both halves); 0.230 -> 0.201 ms on the colour stem.  With 3 gathered channels
+    // (the RGB head's data gradient) the paired loop measured slower (0.71 -> 0.83 ms) and the one-channel loop above stays.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    for (int oc = 2 * wave; oc < OC; oc += 8) {
+        f32x2 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int rc = 0; rc < RC; ++rc)
+#pragma unroll
+            for (int ra = 0; ra < 3; ++ra)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const f32x2 w = *reinterpret_cast<const f32x2*>(&wl[(rc * 9 + perm[ra * 3 + b]) * OCp + oc]);   // wave-uniform address: LDS broadcast
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) o[p] += w * v[rc][p + ra][b];
+                }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (oc + h >= OC) break;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float* q = yb + (int64_t)(oh0 + p) * a.y_sh + (int64_t)(oc + h) * a.y_sc;
+                float x = o[p][h];
+                if (accumulate) x += *q;
+                *q = apply_act(x, act, slope);
+            }
         }
     }
 }
@@ -1293,8 +1344,9 @@ __global__ __launch_bounds__(256) void thin_quad_kernel(const QuadArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, hw = lane >> 5;
     const uint32_t qb = (uint32_t)a.SH >> 2;                       // blocks per plane: 4 quad rows each
-    const uint32_t plane = blockIdx.x / qb;
-    const int r0 = (int)(blockIdx.x - plane * qb) * 4 + 2 * hw;    // this half-wave's first quad row (= gathered row)
+    const uint32_t plane = blockIdx.x / qb;                        // (plain numbering: the XCD plane map of thin_rows_kernel measured slower here,
+    const int r0 = (int)(blockIdx.x - plane * qb) * 4 + 2 * hw;    //  3-D stems 0.26 -> 0.34 ms — neighbouring output depths share their input planes)
+                                                                   // this half-wave's first quad row (= gathered row)
     const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
     // the 4 gathered rows r0 - 1 .. r0 + 2: element offsets inside a (channel, depth) plane, or -1 outside the tensor
     int roff[4];
