@@ -4,7 +4,8 @@ import numpy as np, torch
 from dcvgan_amd import native as N, ops
 from dcvgan_amd.native import dims5, ptr, stream_ptr
 dev = torch.device("cuda:0")
-L = C.CDLL("dcvgan_amd/libdcvgan_hip_stamp.so")
+import os
+L = C.CDLL(os.environ.get("DCV_STAMP_LIB", "/tmp/libdcvgan_hip_stamp.so"))   # tools/build_stamp.sh
 Fr = 1120
 x = torch.randn(Fr, 128, 32, 32, device=dev); w = torch.randn(128, 64, 4, 4, device=dev) * 0.05
 g = ops.conv_geom(w, (2, 2), (1, 1), True)

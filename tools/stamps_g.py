@@ -4,7 +4,8 @@ import numpy as np, torch
 from dcvgan_amd import native as N, ops
 from dcvgan_amd.native import dims5, ptr, stream_ptr
 dev = torch.device("cuda:0")
-L = C.CDLL("dcvgan_amd/libdcvgan_hip_stamp.so")
+import os
+L = C.CDLL(os.environ.get("DCV_STAMP_LIB", "/tmp/libdcvgan_hip_stamp.so"))   # tools/build_stamp.sh
 Lp = C.CDLL("dcvgan_amd/libdcvgan_hip.so")
 Fr = 1120
 CASES = {"up5": (True, 128, 64, 32), "up3": (True, 512, 128, 8), "down1": (False, 64, 128, 32), "down2": (False, 128, 256, 16)}
