@@ -284,13 +284,14 @@ def test_iteration_is_bitwise_reproducible(dev):
     g = torch.Generator().manual_seed(3)
     xc = (torch.rand(6, 3, 16, 64, 64, generator=g) * 2 - 1).to(dev); xg = (torch.rand(6, 1, 16, 64, 64, generator=g) * 2 - 1).to(dev)
 
-    def run():
+    def run(side_streams=True):
         torch.manual_seed(11)
         models = trainer.build_models(cfg, dev)
         r = PhiloxRng(5)
         for m in models.values():
             m._rng = r
-        runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
+        runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True, side_streams=side_streams)
+        assert (runner._lanes is not None) == side_streams
         losses = [runner.step(xc, xg, 2 + i) for i in range(2)]
         return losses, torch.cat([v.detach().float().reshape(-1) for m in models.values() for v in m.state_dict().values()]).cpu()
 
@@ -298,3 +299,7 @@ def test_iteration_is_bitwise_reproducible(dev):
     l2, p2 = run()
     assert l1 == l2
     assert torch.equal(p1, p2)
+    # ... and the discriminators' side streams change the schedule on the device, not one bit of the result
+    l3, p3 = run(side_streams=False)
+    assert l1 == l3
+    assert torch.equal(p1, p3)
