@@ -7,9 +7,14 @@ dev = torch.device("cuda:0")
 import os
 L = C.CDLL(os.environ.get("DCV_STAMP_LIB", "/tmp/libdcvgan_hip_stamp.so"))   # tools/build_stamp.sh
 Fr = 1120
-x = torch.randn(Fr, 128, 32, 32, device=dev); w = torch.randn(128, 64, 4, 4, device=dev) * 0.05
-g = ops.conv_geom(w, (2, 2), (1, 1), True)
-y = torch.randn(Fr, 64, 64, 64, device=dev); dw = torch.empty_like(w)
+if len(sys.argv) > 1 and sys.argv[1] == "down0":   # cgen.down0: Conv2d(64, 64, 4, 2, 1) at 64x64 -> the 64 x 128 tile (TD = 1)
+    x = torch.randn(Fr, 64, 64, 64, device=dev); w = torch.randn(64, 64, 4, 4, device=dev) * 0.05
+    g = ops.conv_geom(w, (2, 2), (1, 1), False)
+    y = torch.randn(Fr, 64, 32, 32, device=dev); dw = torch.empty_like(w)
+else:                                               # cgen.up5: ConvTranspose2d(128, 64, 4, 2, 1) at 32x32 -> the 128 x 128 tile
+    x = torch.randn(Fr, 128, 32, 32, device=dev); w = torch.randn(128, 64, 4, 4, device=dev) * 0.05
+    g = ops.conv_geom(w, (2, 2), (1, 1), True)
+    y = torch.randn(Fr, 64, 64, 64, device=dev); dw = torch.empty_like(w)
 xd, yd = dims5(x), dims5(y)
 L.dcv_conv_workspace_bytes.restype = C.c_size_t
 need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 2)
