@@ -47,11 +47,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as they are read from LDS.  Throughput-only mode (BASELINE configs[2], [4]).
 std::atomic<int> g_precision{0};
 
+// four v_cvt_pk_bf16_f32 (pairs converted as 2-vectors and laid side by side as dwords; element-wise conversion made the compiler
+// convert some values singly and merge them with v_perm / v_alignbit: 80 conversions + 64 merges per 64-position tile of the
+// weight-gradient kernel instead of 64 + 0)
 __device__ __forceinline__ bf16x8 pack_bf16x8(const float (&t)[8]) {
-    bf16x8 r;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    u32x4_ w;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[q] = (__bf16)t[q];
-    return r;
+    for (int q = 0; q < 4; ++q) {
+        const f32x2_ f = {t[2 * q], t[2 * q + 1]};
+        w[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_));
+    }
+    return __builtin_bit_cast(bf16x8, w);
 }
 
 #ifdef DCV_STAMP
@@ -1793,8 +1802,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
             // 16 s + 8 lhi .. + 7 of its channel row.  The next tile's DR + 32 row DMAs go out first.
 #pragma unroll
             for (int q = 0; q < 32; ++q) { if (q < DR) { DCV_WG_DROW(buf ^ 1, q < DR ? q : 0) } DCV_WG_GROW(buf ^ 1, q) }
-            const float* da0 = da - lhi;
-            const float* gb0 = gb - lhi;
+            // one base register per 32-row block, opaque to the optimiser: every fragment word is then base + a small immediate
+            // (folded into ONE base the row-block offsets exceed ds_read2's 8-bit offset field and each read got its own v_add)
+            uint32_t dao[2] = {(uint32_t)(da - smem) + 7 * lhi, (uint32_t)(da - smem) + 7 * lhi + (TD > 1 ? 32 * P : 0)};
+            uint32_t gbo[2] = {(uint32_t)(gb - smem) + 7 * lhi, (uint32_t)(gb - smem) + 7 * lhi + 32 * P};
+            asm volatile("" : "+v"(dao[0]), "+v"(dao[1]), "+v"(gbo[0]), "+v"(gbo[1]));
+            const float* dab[2] = {smem + dao[0], smem + dao[1]};
+            const float* gbb[2] = {smem + gbo[0], smem + gbo[1]};
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
                 bf16x8 a8[TD], b8[2];
@@ -1803,11 +1817,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
                     float t[8];
                     if (i < TD) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) t[q] = da0[i * 32 * P + 16 * sb + 8 * lhi + q];
+                        for (int q = 0; q < 8; ++q) t[q] = dab[i][16 * sb + q];
                         a8[i < TD ? i : 0] = pack_bf16x8(t);
                     }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) t[q] = gb0[i * 32 * P + 16 * sb + 8 * lhi + q];
+                    for (int q = 0; q < 8; ++q) t[q] = gbb[i][16 * sb + q];
                     b8[i] = pack_bf16x8(t);
                 }
 #pragma unroll
