@@ -2063,6 +2063,33 @@ __global__ __launch_bounds__(256) void thin_wgrad3_kernel(const ThinWgradArgs a)
 // dw[dc][j] = sum_s slab[s][dc][j].  64 outputs per block; the 4 waves each sum every 4th split
 // (independent loads, 4-way unrolled) and wave 0 combines the four partial sums in a fixed order:
 // bitwise reproducible, and 16x more loads in flight than one thread walking all S splits.
+// J % 4 == 0 (every 4x4-tap layer): four consecutive j per lane, 16-byte loads — the same order of additions per element
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp) {
+    __shared__ float4 part[3][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int J4 = J >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool ok = i < (int64_t)DC * J4;
+    const int dc = ok ? (int)(i / J4) : 0, j = ok ? (int)(i % J4) * 4 : 0;
+    const int64_t stride = ((int64_t)DCp * Jp) >> 2;
+    const float4* p = reinterpret_cast<const float4*>(slab + (int64_t)dc * Jp + j);
+    float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    int k = grp;
+    for (; k + 12 < S; k += 16) {
+        const float4 t0 = p[(int64_t)k * stride], t1 = p[(int64_t)(k + 4) * stride], t2 = p[(int64_t)(k + 8) * stride], t3 = p[(int64_t)(k + 12) * stride];
+        add(s0, t0); add(s1, t1); add(s2, t2); add(s3, t3);
+    }
+    for (; k < S; k += 4) add(s0, p[(int64_t)k * stride]);
+    const float4 v = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+    if (grp > 0) part[grp - 1][lane] = v;
+    __syncthreads();
+    if (grp == 0 && ok) {
+        const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane];
+        *reinterpret_cast<float4*>(dw + (int64_t)dc * J + j) = float4{((v.x + a.x) + b.x) + c.x, ((v.y + a.y) + b.y) + c.y, ((v.z + a.z) + b.z) + c.z, ((v.w + a.w) + b.w) + c.w};
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp) {
     __shared__ float part[3][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -3047,7 +3074,10 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     else launch_wgrad<1, 1, 1, 4>(a, tiles, S2, stream);
     DCV_LAUNCH_CHECK();
     const int64_t tot = (int64_t)DC * J;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp);
+    if (J % 4 == 0 && Jp % 4 == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((tot / 4 + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
