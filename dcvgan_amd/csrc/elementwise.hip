@@ -690,11 +690,12 @@ __global__ __launch_bounds__(64) void gru_fwd_kernel(const float* __restrict__ e
 // per-sample BPTT; partial parameter gradients go to part[b][P], P = 6*dm*dm + 6*dm,
 // layout [dw_ih (3dm*dm) | dw_hh (3dm*dm) | db_ih (3dm) | db_hh (3dm)]
 __global__ __launch_bounds__(64) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ e, const float* __restrict__ h0, const float* __restrict__ out,
-                                                     const float* __restrict__ gates, const float* __restrict__ w_hh, float* __restrict__ part, int T, int B, int dm) {
+                                                     const float* __restrict__ gates, const float* __restrict__ w_hh, float* __restrict__ part, int T, int B, int dm, int lds_acc) {
     __shared__ float dgh[3 * GRU_MAXD], dh[GRU_MAXD];
+    extern __shared__ float gru_acc[];   // lds_acc: the sample's P partial sums (the same additions in the same order, just not through global memory)
     const int b = blockIdx.x, u = threadIdx.x;
     const int P = 6 * dm * dm + 6 * dm;
-    float* pp = part + (int64_t)b * P;
+    float* pp = lds_acc ? gru_acc : part + (int64_t)b * P;
     for (int i = u; i < P; i += 64) pp[i] = 0.f;
     if (u < dm) dh[u] = 0.f;
     __syncthreads();
@@ -735,6 +736,10 @@ __global__ __launch_bounds__(64) void gru_bwd_kernel(const float* __restrict__ d
             dh[u] = s;
         }
         __syncthreads();
+    }
+    if (lds_acc) {
+        float* out_p = part + (int64_t)b * P;
+        for (int i = u; i < P; i += 64) out_p[i] = pp[i];
     }
 }
 
@@ -1264,9 +1269,10 @@ int dcv_gru_backward(const float* dout, const float* e, const float* h0, const f
     if (!ws || ws_bytes < dcv_gru_workspace_bytes(B, dm)) return fail(DCV_EWORKSPACE, "gru_backward: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(64), 0, s, dout, e, h0, out, gates, w_hh, part, T, B, dm);
-    DCV_LAUNCH_CHECK();
     const int P = 6 * dm * dm + 6 * dm;
+    const int lds_acc = (size_t)P * sizeof(float) <= 48 * 1024;   // dm <= 44: the partial sums live in LDS
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(B), dim3(64), lds_acc ? (size_t)P * sizeof(float) : 0, s, dout, e, h0, out, gates, w_hh, part, T, B, dm, lds_acc);
+    DCV_LAUNCH_CHECK();
     hipLaunchKernelGGL(gru_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, s, part, B, P, dm, dw_ih, dw_hh, db_ih, db_hh);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
