@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """videos/s of the DCVGAN G+D training iteration on MI355X (default: config/isogd-depth.yml, B = 70 per GPU, fp32).
 
-    python bench.py --gpus 1 --steps K --warmup W [--config isogd-depth|surreal-depth1|isogd-flow]
+    python bench.py --gpus N --steps K --warmup W [--config isogd-depth|surreal-depth1|isogd-flow]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Both forms work for N > 1: under a launcher (WORLD_SIZE set) this process IS a rank; without one the parent — before any
+HIP call — starts N fresh child processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set),
+relays rank 0's JSON line and exits non-zero if any rank fails or BENCH_TIMEOUT (default 1500 s) passes.
 
 One step = the reference trainer's iteration (trainer.py:279-363): D phase (3 D's on the real and the fake batch,
 backward, 3 Adam steps — gated by num_gen_update) + G phase (fresh fakes, backward, ggen / cgen / ggen Adam steps),
@@ -52,9 +56,69 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: MFMA products in bf16 with fp32 accumulation in the large GEMM kernels (tensors, weights, statistics and "
                          "optimiser state stay fp32) — a secondary throughput line for BASELINE configs[2]/[4], not the headline")
-    ap.add_argument("--minimal", action="store_true", help="also time the schedule with the dead D-phase generator backward elided (secondary line)")
-    ap.add_argument("--no-minimal", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--minimal", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--no-minimal", action="store_true", help="skip the secondary `minimal_schedule` key (the schedule with the dead D-phase generator backward elided, "
+                                                              "timed AFTER the headline region) — profile runs use this so that the trace holds the as-written schedule only")
+    ap.add_argument("--cpus", type=int, default=0, help="pin this rank to K host CPUs (host-headroom probe: 8 ranks on a 16-CPU share have 2 each)")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher.  The parent never touches the GPU (torch.cuda.device_count() does not
+    initialise HIP on this image): the ranks are fresh children, never a re-exec of a process that holds the device."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if a.gpus > have and not a.all_ranks_on_device0:
+        print(f"bench.py: --gpus {a.gpus} but only {have} visible (use --all-ranks-on-device0 --backend gloo to rehearse on one card)", file=sys.stderr)
+        return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get("BENCH_TIMEOUT", "1500"))
+    rc, out0 = 0, b""
+    try:
+        import threading
+        buf = []
+        rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)   # drain rank 0's pipe while we poll
+        rd.start()
+        live = set(range(a.gpus))
+        while live and rc == 0:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0:
+                        print(f"bench.py: rank {r} exited with code {c}", file=sys.stderr)
+                        rc = c if c > 0 else 1
+            if time.time() > deadline:
+                print("bench.py: BENCH_TIMEOUT passed", file=sys.stderr)
+                rc = 124
+            if live and rc == 0:
+                time.sleep(0.2)
+        if rc == 0:
+            rd.join(10)
+            out0 = buf[0] if buf else b""
+    finally:
+        for p in procs:            # exactly the PIDs started above
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(10)
+            except Exception:
+                pass
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.startswith("{")]
+    if rc == 0 and not lines:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        print(lines[-1], flush=True)
+    return rc
 
 
 def dominant_kernel_probe(models, cfg, dev):
@@ -83,16 +147,22 @@ def dominant_kernel_probe(models, cfg, dev):
     return {"layer": "cgen.up_blocks.5 forward", "kernel": name, "ms": ms, "gflop_per_launch": flops / 1e9, "tflops": flops / ms / 1e9}
 
 
-def committed_traffic(batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/round_profile.sh -> tools/dominant_pmc.py; FETCH_SIZE
-    doubled for the 16-byte-per-lane operand streams as the MI355X guide prescribes) — only when it was taken at this batch."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")))
-        if int(t.get("batch", -1)) == int(batch):
+def committed_traffic(batch, kernel):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (tools/round_profile.sh ->
+    tools/dominant_pmc.py; FETCH_SIZE doubled for the 16-byte-per-lane operand streams as the MI355X guide prescribes).  PMC counters
+    cannot be collected from inside this process, so the figure is only reported when the profile was taken at THIS batch size from the
+    kernel instance this run just launched (`dcv_debug_last_kernel`); otherwise null — a stale number is worse than none."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dominant_kernel_pmc.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if int(t.get("batch", -1)) == int(batch) and t.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
             return t["hbm_bytes_per_launch"], {"algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "unit": "bytes per launch",
-                                               "source": "profiles/r02_dominant_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)"}
-    except Exception:
-        pass
+                                               "traffic_over_algorithmic": t.get("traffic_over_algorithmic"), "profiled_at_git_head": t.get("git_head"),
+                                               "source": f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)"}
+        return None, {"note": f"profiles/{os.path.basename(f)} was taken from kernel {t.get('kernel')!r} at batch {t.get('batch')}; this run launched {kernel!r} at batch {batch}"}
     return None, None
 
 
@@ -142,9 +212,15 @@ def cpu_baseline(cfg, batch, steps):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.cpus:
+        mine = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(mine[(rank * a.cpus) % len(mine):][:a.cpus]) or set(mine[:a.cpus]))
+    torch.set_num_threads(max(1, host_threads() // max(1, world)))    # N ranks share the host's CPU quota
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     if a.all_ranks_on_device0:
         local = 0
@@ -213,7 +289,7 @@ def main():
 
     # secondary, clearly labelled and off by default: identical parameter updates, the dead D-phase generator backward elided
     minimal = None
-    if a.minimal:
+    if not a.no_minimal:
         runner2 = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=False, elide_dead_backward=True)
         runner2.iteration = runner.iteration
         runner2.step(xc, xg, 0)
@@ -231,7 +307,7 @@ def main():
         step_tflops = f_step * (B / per_step) / 1e12        # per GPU
         probe = dominant_kernel_probe(models, cfg, dev)
         gb_step = ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION * B
-        traffic, traffic_detail = committed_traffic(B) if a.precision == "fp32" else (None, None)
+        traffic, traffic_detail = committed_traffic(B, probe["kernel"]) if a.precision == "fp32" else (None, None)
         gating = "" if cfg.num_gen_update == 1 else f", D update every {cfg.num_gen_update} iterations (FLOPs averaged over the cycle)"
         line = {
             "metric": "videos/sec per G+D step, 16x64x64 RGB+depth" if cfg.channel == 1 else "videos/sec per G+D step, 16x64x64 RGB+flow",
@@ -243,6 +319,8 @@ def main():
                        "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup)},
             "roofline": {"bound": "mfma", "achieved": probe["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": probe["tflops"] / peak, "traffic": traffic, "traffic_detail": traffic_detail,
+                         "definition": "achieved / frac = the DOMINANT KERNEL timed alone (rounds 2+; round 1's BENCH line carried the whole-step figure "
+                                       "here — compare rounds on roofline.step.frac, which has been the same quantity throughout)",
                          "kernel": probe,
                          "step": {"achieved": step_tflops, "frac": step_tflops / peak, "flops_per_video_step": f_step},
                          "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,

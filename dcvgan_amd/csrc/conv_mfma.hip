@@ -2295,6 +2295,10 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         if (half) tc.bm /= 2;
     }
     if (gate && tc.bn == 4) return fail(DCV_EUNSUPPORTED, "%s: the gated epilogue is not built into the thin (OC <= 4) kernels", tag);
+    if (gate)   // a stride-parity class without taps (stride > kernel) has positions no workgroup visits: they would stay un-gated
+        for (const GatherClass& c : classes)
+            if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 && c.o_ext[0] > 0 && c.o_ext[1] > 0 && c.o_ext[2] > 0)
+                return fail(DCV_EUNSUPPORTED, "%s: gated epilogue with a tap-less position class", tag);
     // packed weights: in the caller's buffer when one is given (and already valid when pack->ready), else in `ws`
     char* const pk_base = pack && pack->buf ? reinterpret_cast<char*>(pack->buf) : nullptr;
     const bool pk_ready = pk_base && pack->ready;

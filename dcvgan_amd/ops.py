@@ -113,14 +113,28 @@ class _PackCache:
         key = (which, g.key(), tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
         e = self.entries.get(key)
         stamp = (w._version, w.data_ptr())
+        if _POISON:
+            # debug builds of the tests: edits autograd cannot see (`p.data.normal_()`, raw-pointer writes) do not bump the version;
+            # a checksum of the live weights in the stamp turns "silently convolving with stale packed weights" into a repack
+            wd = w.detach().double()
+            stamp = stamp + (float(wd.sum()), float(wd.abs().sum()))
         if e is None:
             nbytes = lib().dcv_conv_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), which)
             if nbytes == 0:
                 return None
             e = self.entries[key] = [None, torch.empty(nbytes, dtype=torch.uint8, device=w.device)]
         ready = e[0] == stamp
-        e[0] = stamp
-        return N.WPack(e[1].data_ptr(), e[1].numel(), int(ready))
+        e[0] = None                     # not valid again until the launch that (re)packs it has been accepted: see commit()
+        pk = N.WPack(e[1].data_ptr(), e[1].numel(), int(ready))
+        pk._entry, pk._stamp = e, stamp
+        return pk
+
+    @staticmethod
+    def commit(pk):
+        """The conv call that consumed `pk` returned success: its packed buffer now holds the weights of `stamp`.  A call that
+        fails (EWORKSPACE, a launch error) never gets here, so a retry packs again instead of reading an unpacked buffer."""
+        if pk is not None:
+            pk._entry[0] = pk._stamp
 
 
 _USE_PACK_CACHE = os.environ.get("DCV_NO_PACK_CACHE") is None
@@ -173,7 +187,7 @@ class _Conv(Function):
         sbytes = L.dcv_conv_stats_bytes(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE) else 0
         if sbytes:
             # conv -> BatchNorm pair: the epilogue leaves per-tile {sum, sum^2} of y, the BN op skips its pass over y
-            stat = torch.empty(sbytes // 4, dtype=torch.float32, device=x.device)
+            stat = _empty((sbytes // 4,), x.device)     # poison runs turn a (class, tile) row no workgroup wrote into NaN statistics
             nparts, pitch = C.c_int(0), C.c_int(0)
             check(L.dcv_conv_forward_stats(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), ptr(stat), sbytes,
                                            C.byref(nparts), C.byref(pitch), pkp, wsp, wsn, stream_ptr()), "dcv_conv_forward_stats")
@@ -181,6 +195,7 @@ class _Conv(Function):
                 bn_stats.append((stat, nparts.value, pitch.value))
         else:
             check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, pkp, wsp, wsn, stream_ptr()), "dcv_conv_forward")
+        _PackCache.commit(pk)
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -226,6 +241,7 @@ class _Conv(Function):
             if rc == N.DCV_EUNSUPPORTED:
                 check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), int(into is not None),
                                                pkp, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
+            _PackCache.commit(pk)
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:

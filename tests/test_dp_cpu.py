@@ -103,3 +103,21 @@ def test_dp_wrapper_world2_gloo():
     for p in procs:
         p.join(30)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_bench_launcher_fails_loudly_without_gpus():
+    """bench.py --gpus N (N > 1, no launcher): the parent spawns the ranks itself.  Here there is no GPU, so (a) asking for more ranks
+    than visible devices is refused before anything starts, (b) in the rehearsal form every rank dies on its `needs an MI355X`
+    assertion and the parent must come back non-zero promptly with no JSON line — never hang, never print a partial result."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "visible" in p.stderr and p.stdout.strip() == ""
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode not in (0, 2) and p.stdout.strip() == "" and "rank" in p.stderr, (p.returncode, p.stderr[-500:])
+    assert time.time() - t0 < 120

@@ -38,3 +38,18 @@ def test_two_ranks_distinct_data(tmp_path):
 def test_two_ranks_same_data_equal_one_process(tmp_path):
     for r in _run("same", tmp_path):
         assert r["replicas_identical"] and r["equals_single_process"] and r["moved"], r
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks itself (fresh children, before any HIP call)
+    and relays rank 0's single JSON line.  Two ranks share the card here, hence gloo (RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo",
+                        "--batch", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-minimal"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
+    assert r["value"] > 0 and r["cpu_baseline"] is None

@@ -5,13 +5,18 @@ streams of this kernel are 16-byte LDS-DMA granules (patch staging + packed weig
 import csv
 import glob
 import json
+import os
+import re
 
 B, N = 70, 10
+KERNEL = [None]
 
 
 def per_dispatch(tag, names):
     f = glob.glob(f"/tmp/pd_{tag}/**/*counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if "gather_gemm_dma_kernel" in r["Kernel_Name"]]
+    m = re.search(r"gather_gemm_dma_kernel<[^>]*>", rows[-1]["Kernel_Name"])
+    KERNEL[0] = m.group(0) if m else rows[-1]["Kernel_Name"]
     out = {}
     for n in names:
         vals = {}
@@ -29,7 +34,7 @@ sq = per_dispatch("SQ", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_
 F = B * 16
 algo = (F * 128 * 32 * 32 + F * 64 * 64 * 64 + 128 * 64 * 16) * 4
 print(json.dumps({
-    "kernel": "gather_gemm_dma_kernel<2, 2, 1, 4, false, true>", "layer": "cgen.up_blocks.5 forward", "batch": B,
+    "kernel": KERNEL[0], "git_head": os.environ.get("GIT_HEAD"), "layer": "cgen.up_blocks.5 forward", "batch": B,
     "fetch_size_bytes_raw": fe, "fetch_size_bytes_corrected_x2": 2 * fe, "write_size_bytes": wr,
     "hbm_bytes_per_launch": 2 * fe + wr, "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": (2 * fe + wr) / algo,
     # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD... normalised as in tools/pmc_step.sh: busy / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)
