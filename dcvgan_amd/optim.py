@@ -174,3 +174,14 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
         for t in ts:
             dist.broadcast(t.data, src, group=group)
         torch.autograd.graph.increment_version(ts)   # `.data` writes bypass the version counter
+
+
+def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None):
+    """BatchNorm running statistics stay per-rank during data-parallel training (each rank = one reference trainer, SURVEY §8(e));
+    call this before a snapshot / evaluation (trainer.py:70-86, :196) when every rank should save rank `src`'s statistics."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for b in module.buffers():
+            dist.broadcast(b.data, src, group=group)

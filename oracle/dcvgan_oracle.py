@@ -104,8 +104,10 @@ class KinkTape:
 
     active = None
 
-    def __init__(self, masks):
+    def __init__(self, masks=None):
+        """`masks=None`: RECORD this evaluation's own patterns into `self.recorded` instead of replaying."""
         self.masks, self.pos, self.mismatch = masks, 0, []
+        self.recorded = [] if masks is None else None
 
     def __enter__(self):
         KinkTape.active = self
@@ -115,6 +117,10 @@ class KinkTape:
         KinkTape.active = None
 
     def next(self, x):
+        if self.recorded is not None:
+            self.recorded.append(x.detach() > 0)
+            self.pos += 1
+            return self.recorded[-1]
         m = self.masks[self.pos]
         self.pos += 1
         assert tuple(m.shape) == tuple(x.shape), (self.pos - 1, tuple(m.shape), tuple(x.shape))
@@ -122,7 +128,7 @@ class KinkTape:
         bad = own != m
         n = int(bad.sum())
         far = float(x.detach()[bad].abs().max() / x.detach().pow(2).mean().sqrt()) if n else 0.0
-        self.mismatch.append((n, x.numel(), far))
+        self.mismatch.append((n, x.numel(), far, tuple(x.shape)))
         return m
 
 

@@ -525,6 +525,10 @@ if __name__ == "__main__":
     lr2 = dict(ggen=2e-4, cgen=2e-4, idis=2e-4, vdis=2e-4, gdis=2e-4)
     step_fullwidth_fixture(ref, full_surreal, "step_fullwidth_surreal_depth1.npz", "hinge-loss", 2, lr2)
     step_fullwidth_fixture(ref, full_flow, "step_fullwidth_isogd_flow.npz", "hinge-loss", 1, lr2, seed=41)
+    # the headline config's own composed iteration: config/isogd-depth.yml:5,27,47-89 — BCE-with-logits, Noise sigma 0.1 on idis / vdis,
+    # lr 5e-4 for idis / vdis (:70,79), 2e-4 for the others
+    lr_isogd = dict(ggen=2e-4, cgen=2e-4, idis=5e-4, vdis=5e-4, gdis=2e-4)
+    step_fullwidth_fixture(ref, full, "step_fullwidth_isogd_depth.npz", "adversarial-loss", 1, lr_isogd, seed=51)
     stress_d_fixture(ref)
     sampling_fixture(ref, dict(small_depth, ngf_g=4, ngf_c=4), "sampling_depth_w4.npz")
     interchange_fixture(ref)

@@ -88,6 +88,11 @@ def _worker(rank, world, port, q):
     dist.all_gather_object(allw, (w0.numpy(), w1.numpy()))
     ok &= all((a[0] == allw[0][0]).all() and (a[1] == allw[0][1]).all() for a in allw)   # replicas stay identical
     ok &= not (w0 == w1).all()
+    # BatchNorm buffers are per-rank state; broadcast_buffers gives every rank rank 0's before a snapshot
+    bn = torch.nn.BatchNorm2d(3)
+    bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(rank + 5)
+    optim.broadcast_buffers(bn)
+    ok &= bool((bn.running_mean == 1.0).all()) and int(bn.num_batches_tracked) == 5
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -34,9 +34,10 @@ def test_fullwidth_generator_pass(fixture):
     assert n > 60
 
 
-@pytest.mark.parametrize("fixture", ["step_fullwidth_surreal_depth1.npz", "step_fullwidth_isogd_flow.npz"])
+@pytest.mark.parametrize("fixture", ["step_fullwidth_isogd_depth.npz", "step_fullwidth_surreal_depth1.npz", "step_fullwidth_isogd_flow.npz"])
 def test_fullwidth_training_step(fixture):
-    """Two iterations of trainer.py:279-363 at full width (hinge; surreal: the D update runs every 2nd iteration)."""
+    """Two iterations of trainer.py:279-363 at full width (isogd-depth: BCE + Noise, the headline config; hinge for the other two; surreal: the D
+    update runs every 2nd iteration)."""
     fx = G.load(fixture)
     cfg, models = FW.same_seed_models(fx)
     cfg.num_gen_update = int(fx["meta/num_gen_update"])
