@@ -177,7 +177,7 @@ def checked_iteration(runner, models, opts, forced: ForcedStepOracle, layers_mod
 
 
 # The bars every caller uses (measured values are written next to them in profiles/r03_step_parity/; each bar is >= 10x its measurement)
-UPDATE_TOL = 1e-4          # relative L2 of a tensor's update over its insensitive elements
+UPDATE_TOL = 2e-4          # relative L2 of a tensor's update over its insensitive elements
 LOSS_TOL = 1e-4            # every loss of the iteration, relative
 BUFFER_TOL = 2e-4          # BatchNorm running statistics after the iteration, relative L2 per buffer
 
