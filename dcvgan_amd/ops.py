@@ -140,25 +140,6 @@ class _PackCache:
 _USE_PACK_CACHE = os.environ.get("DCV_NO_PACK_CACHE") is None
 _SKIP_ACCUMULATE = os.environ.get("DCV_NO_SKIP_ACCUMULATE") is None
 _GATED_DGRAD = os.environ.get("DCV_NO_GATED_DGRAD") is None
-# Experiment (off by default; profiles/r03_ab_wgrad_stream.txt): weight gradients on a low-priority side stream, released by an event
-# recorded after the same layer's data gradient, so that they run beside the NEXT layer's BatchNorm-backward passes (HBM-bound, no
-# LDS) rather than in front of them.  The side stream is joined before anything reads the gradient: at once when autograd will add
-# it into an existing .grad, else by join_wgrad_stream() (trainer.StepRunner, after backward()).
-_WGRAD_SIDE = os.environ.get("DCV_WGRAD_STREAM") is not None
-_wgrad_streams = {}
-
-
-def _wgrad_stream(device):
-    s = _wgrad_streams.get(device.index)
-    if s is None:
-        lo, _hi = torch.cuda.Stream.priority_range()     # (least, greatest): least = the numerically largest value
-        s = _wgrad_streams[device.index] = torch.cuda.Stream(device, priority=lo)
-    return s
-
-
-def join_wgrad_stream():
-    for s in _wgrad_streams.values():
-        torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 def _pack_of(w):
@@ -263,18 +244,7 @@ class _Conv(Function):
             _PackCache.commit(pk)
             if into is not None:
                 dx = None
-        if ctx.needs_input_grad[1] and _WGRAD_SIDE and torch.cuda.current_stream() == torch.cuda.default_stream():
-            main, side = torch.cuda.current_stream(), _wgrad_stream(x.device)
-            side.wait_event(main.record_event())          # dy (and this layer's data gradient) are complete
-            with torch.cuda.stream(side):
-                dw = _empty(w.shape, w.device)
-                need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
-                wsp, wsn = _ws("conv", need, x.device)
-                check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
-            x.record_stream(side); dy.record_stream(side); dw.record_stream(main)
-            if w.grad is not None:                         # autograd will `+=` it on the main stream right after this node
-                main.wait_stream(side)
-        elif ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1]:
             dw = _empty(w.shape, w.device)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)

@@ -21,7 +21,7 @@ import torch
 from . import discriminator as D
 from . import generator as G
 from . import loss as Lm
-from . import ops, optim, util
+from . import optim, util
 from .configs import StepConfig
 
 MODEL_NAMES = ("ggen", "cgen", "idis", "vdis", "gdis")
@@ -127,7 +127,6 @@ class StepRunner:
         loss_dis = loss_idis + loss_vdis + loss_gdis
         if self.iteration % c.num_gen_update == 0:
             loss_dis.backward()
-            ops.join_wgrad_stream()
             o["idis"].step(); o["vdis"].step(); o["gdis"].step()
         else:
             loss_dis.detach_()
@@ -144,7 +143,6 @@ class StepRunner:
         loss_gen = self.loss.compute_gen_loss(*y_fake)
         if self.iteration % c.num_dis_update == 0:
             loss_gen.backward()
-            ops.join_wgrad_stream()
             o["ggen"].step(); o["cgen"].step(); o["ggen"].step()  # ggen twice — trainer.py:357-359
         else:
             loss_gen.detach_()
