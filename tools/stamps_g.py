@@ -36,5 +36,8 @@ for name in sys.argv[1:] or ["up5"]:
     nb = int((b[:, 0, 5] > 0).sum())
     s = b[:nb]
     n = s[..., 5].mean()
+    pro = s[..., 0].mean(axis=1)
+    print(name, "prologue cycles by block id: <1024: %.0f   1024-2047: %.0f   >=2048: %.0f | percentiles 10/50/90: %s" % (
+        pro[:1024].mean(), pro[1024:2048].mean() if nb > 1024 else 0, pro[2048:].mean() if nb > 2048 else 0, np.percentile(pro, [10, 50, 90]).round()))
     print(name, "blocks(stamped)", nb, "steps/block %.0f | per wave: prologue %.0f  epilogue %.0f  per step: wait+barrier %.0f  mfma-loop %.0f | final-wait %.0f lifetime %.0f" % (
         n, s[..., 0].mean(), s[..., 3].mean(), s[..., 1].sum() / s[..., 5].sum(), s[..., 2].sum() / s[..., 5].sum(), fw[:nb].mean(), s[..., 4].mean()))
