@@ -64,13 +64,15 @@ def test_conv_bf16_products(bf16, case):
         assert "bf16" in kernel and errs[0] > 2e-4, (kernel, errs)   # the bf16 instance ran (an fp32 one would sit at ~1e-7)
 
 
-def test_training_iteration_in_bf16_mode(bf16):
-    """One full-width isogd-depth iteration at B = 4: finite losses, parameters move, forward within 3e-2 of the fp32 mode."""
+@pytest.mark.parametrize("name", ["isogd-depth", "surreal-depth1", "isogd-flow"])
+def test_training_iteration_in_bf16_mode(bf16, name):
+    """One full-width iteration at B = 4 of each GPU config (surreal-depth1 is the one BASELINE configs[2] names for bf16; isogd-flow the
+    one configs[4] names for the 16-bit MFMA path): finite losses, parameters move, forward within 3e-2 of the fp32 mode."""
     from dcvgan_amd import native, trainer
     from dcvgan_amd.configs import CONFIGS
     from dcvgan_amd.rng import PhiloxRng
     dev = bf16
-    cfg = CONFIGS["isogd-depth"].scaled(batchsize=4)
+    cfg = CONFIGS[name].scaled(batchsize=4, num_gen_update=1)
     torch.manual_seed(5)
     models = trainer.build_models(cfg, dev)
 
@@ -90,7 +92,7 @@ def test_training_iteration_in_bf16_mode(bf16):
     before = torch.cat([p.detach().reshape(-1) for p in models["cgen"].parameters()]).clone()
     runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
     g = torch.Generator().manual_seed(1)
-    xc = (torch.rand(4, 3, 16, 64, 64, generator=g) * 2 - 1).to(dev); xg = (torch.rand(4, 1, 16, 64, 64, generator=g) * 2 - 1).to(dev)
+    xc = (torch.rand(4, 3, 16, 64, 64, generator=g) * 2 - 1).to(dev); xg = (torch.rand(4, cfg.channel, 16, 64, 64, generator=g) * 2 - 1).to(dev)
     out = runner.step(xc, xg, 3)
     assert all(v == v and abs(v) < 100 for v in out.values()), out
     after = torch.cat([p.detach().reshape(-1) for p in models["cgen"].parameters()])
