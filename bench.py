@@ -158,7 +158,8 @@ def committed_traffic(batch, kernel):
             t = json.load(open(f))
         except Exception:
             continue
-        if int(t.get("batch", -1)) == int(batch) and t.get("kernel", "").replace(" ", "") == kernel.replace(" ", ""):
+        inst = lambda k: k.split(" (")[0].replace(" ", "")      # template instance without the library's "(tile, classes)" annotation
+        if int(t.get("batch", -1)) == int(batch) and inst(t.get("kernel", "")) == inst(kernel):
             return t["hbm_bytes_per_launch"], {"algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "unit": "bytes per launch",
                                                "traffic_over_algorithmic": t.get("traffic_over_algorithmic"), "profiled_at_git_head": t.get("git_head"),
                                                "source": f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)"}

@@ -39,6 +39,25 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
+GUARD = 8192     # elements of NaN on either side of every operand
+
+
+def guarded(t):
+    """The same values inside a NaN-filled allocation, same shape and strides: a read that strays outside the tensor — a halo granule that
+    should have been padding, an offset past the last sample — puts a NaN into the result instead of whatever the allocator left next door
+    (the raw-buffer descriptors range-check against 2 GB, not against the tensor).  -> (view, storage)"""
+    base = t
+    while base._base is not None:
+        base = base._base
+    big = torch.full((base.numel() + 2 * GUARD,), float("nan"), device=t.device, dtype=t.dtype)
+    big[GUARD:GUARD + base.numel()] = base.reshape(-1)
+    return torch.as_strided(big, t.shape, t.stride(), GUARD + t.storage_offset()), big
+
+
+def margins_intact(big, n):
+    return bool(torch.isnan(big[:GUARD]).all() and torch.isnan(big[GUARD + n:]).all())
+
+
 @pytest.fixture(scope="module")
 def dev():
     from dcvgan_amd import native
@@ -51,11 +70,15 @@ def test_layer_at_b70(dev, case):
     from dcvgan_amd import ops
     name, tr, cin, cout, k, s, p, xs = case
     g = torch.Generator(device=dev).manual_seed(11)
-    xd = torch.randn(xs, device=dev, generator=g).requires_grad_(True)
-    wd = (torch.randn(((cin, cout) if tr else (cout, cin)) + k, device=dev, generator=g) * 0.05).requires_grad_(True)
+    xd, xbig = guarded(torch.randn(xs, device=dev, generator=g))
+    xd.requires_grad_(True)
+    wd, wbig = guarded(torch.randn(((cin, cout) if tr else (cout, cin)) + k, device=dev, generator=g) * 0.05)
+    wd.requires_grad_(True)
     y = ops.conv(xd, wd, ops.conv_geom(wd, s, p, tr))
-    cotd = torch.randn(y.shape, device=dev, generator=g)
+    cotd, cbig = guarded(torch.randn(y.shape, device=dev, generator=g))
     gx, gw = torch.autograd.grad((y * cotd).sum(), [xd, wd])
+    assert bool(torch.isfinite(y).all() and torch.isfinite(gx).all() and torch.isfinite(gw).all()), name        # nothing outside the operands was read
+    assert margins_intact(xbig, xd.numel()) and margins_intact(wbig, wd.numel()) and margins_intact(cbig, cotd.numel()), name            # ... or written
     x, w, cot = xd.detach().cpu().requires_grad_(True), wd.detach().cpu().requires_grad_(True), cotd.cpu()
     fn = F.conv_transpose2d if tr else (F.conv3d if len(k) == 3 else F.conv2d)
     y_ref = fn(x, w, None, s, p)
