@@ -118,7 +118,7 @@ struct GatherArgs {
     // instead of 8-16.
     int32_t patch, p_G, p_log2nh, p_log2tr;   // granules per step; rows per (channel, output row); output rows per tile
     int32_t p_log2ow, p_iwp, p_ihmin, p_iwmin4;
-    int32_t p_dw1, p_sc4, p_pad1, p_pad2;     // word step from an even k row to the next (tap uw -> uw + 1); channel stride in bytes
+    int32_t p_dw1, p_sc4, slab_mp, p_pad2;    // word step from an even k row to the next (tap uw -> uw + 1); channel stride in bytes; slab_mp: see rag_m0
     FastDiv p_gpr;                            // granules per patch row = IW / 4 + 2
     // BatchNorm statistics of the output, fused into the epilogue: stat[(class * stat_ntm + m tile)][OCp][2] =
     // {sum, sum of squares} over the tile's positions (fp32, <= 256 terms each; combined in fp64 by the BN op)
@@ -128,7 +128,11 @@ struct GatherArgs {
     // conv's input, taken from that input itself (gate has y's shape and strides); nullptr = off
     const float* gate;
     float gate_slope;
-    int32_t pad3;
+    // ragged split-K (LDS-DMA kernel): only the position tiles from rag_m0 on — the ones that would otherwise run as an under-filled
+    // last round of the chip's 1024 resident workgroups — are split over blockIdx.y and go through slab[y][oc][m - rag_m0] (pitch
+    // slab_mp) + splitk_reduce_kernel; the tiles before it take the direct epilogue and exist for blockIdx.y == 0 only.
+    // Plain split-K: rag_m0 = 0, slab_mp = Mp.
+    int32_t rag_m0;
 };
 
 // up to 4 stride-parity classes of one scatter-form op run as ONE launch (blockIdx.z = class):
@@ -557,6 +561,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     const int oc0 = oc_t * BN;
     const int m0 = m_t * BM;
     if (m0 >= a.Mp) return;   // grid padding; classes of one launch can differ by a row/column of positions
+    const bool slabmode = a.slab != nullptr && m0 >= a.rag_m0;
+    if (!slabmode && blockIdx.y != 0) return;   // ragged split-K: a directly stored tile exists once
 
     const uint32_t n0 = fdiv((uint32_t)m0, a.div_sp);
     // DSTEP: the scalar depth-tap offset counts up from the farthest tap, so the base sits x_back elements
@@ -733,8 +739,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int it0 = a.slab ? blockIdx.y * a.kper : 0;
-    const int it1 = a.slab ? min(a.KIT, it0 + a.kper) : a.KIT;
+    const int it0 = slabmode ? blockIdx.y * a.kper : 0;
+    const int it1 = slabmode ? min(a.KIT, it0 + a.kper) : a.KIT;
     const int nst = it1 - it0;
 #define DCV_IT(J) (it0 + (J))
     int j0 = 0;
@@ -858,8 +864,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #define DCV_STAMP_OUT()
 #endif
 
-    if (a.slab) {
-        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.Mp;
+    if (slabmode) {
+        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.OCp * a.slab_mp;
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -867,7 +873,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int oc = oc0 + (woc * TOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    sl[(int64_t)oc * a.Mp + m0 + (wm * TM + j) * 32 + l31] = acc[i][j][r];
+                    sl[(int64_t)oc * a.slab_mp + (m0 - a.rag_m0) + (wm * TM + j) * 32 + l31] = acc[i][j][r];
                 }
         DCV_STAMP_OUT()
         return;
@@ -881,11 +887,12 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GatherArgsPack pack, int S) {
     // 4 consecutive positions per thread (16-byte slab loads), 4 slabs in flight; 32-bit index math
     const GatherArgs& a = pack.c[blockIdx.y];
-    const uint32_t Mp = (uint32_t)a.Mp, M = (uint32_t)a.M, q4 = Mp >> 2;
+    const uint32_t Mp = (uint32_t)a.slab_mp, M = (uint32_t)a.M, q4 = Mp >> 2;   // the slab's own pitch: the whole op, or its ragged tail from rag_m0 on
+    if (q4 == 0) return;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t oc = idx / q4, m = (idx - oc * q4) * 4;
+    const uint32_t oc = idx / q4, ml = (idx - oc * q4) * 4, m = ml + (uint32_t)a.rag_m0;
     if (oc >= (uint32_t)a.OC || m >= M) return;
-    const float4* __restrict__ p = reinterpret_cast<const float4*>(a.slab + (int64_t)oc * Mp + m);
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(a.slab + (int64_t)oc * Mp + ml);
     const int64_t stride = ((int64_t)a.OCp * Mp) >> 2;
     float4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
     int k = 0;
@@ -2130,11 +2137,13 @@ static std::map<std::string, DevTable> g_tables;   // keys start with the device
 struct Toggles {
     bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64, no_quad, no_thin_wgrad;
     int half_m;
+    bool no_ragged;
     Toggles() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
         no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD"); no_thin_wgrad = on("DCV_NO_THIN_WGRAD");
         half_m = getenv("DCV_HALF_M") ? atoi(getenv("DCV_HALF_M")) : -1;
+        no_ragged = on("DCV_NO_RAGGED");
     }
 };
 static const Toggles& toggles() {
@@ -2205,6 +2214,28 @@ static void launch_gather(const GatherArgs& a, dim3 grid, hipStream_t s) {
     else hipLaunchKernelGGL((gather_gemm_kernel<TOC, TM, WOC, WM, false>), grid, dim3(256), 0, s, a);
 }
 
+// Ragged split-K.  An op whose W workgroups (all classes, one launch) make F whole rounds of the chip's 1024 resident workgroups plus
+// a small remainder E runs that remainder as an under-filled last round: the few CUs that still have a workgroup run ONE wave per
+// SIMD, which cannot keep the matrix pipe busy by itself, for a whole tile's K loop (cgen.up2 at B = 70: 1120 tiles = 1 round + 96:
+// 5.3 units of time against 4.375 if the work were spread evenly).  Instead the position tiles of the remainder — t1 on — are split
+// over K into k parts each (blockIdx.y; ids with y > 0 are dispatched after all of y == 0, so the parts fill the chip behind the
+// whole tiles), sized so that every SIMD has at least two waves: k = ceil(512 / E).  Partial sums go through the slab and
+// splitk_reduce_kernel in a fixed order, as for plain split-K, so results stay bitwise reproducible.
+struct RagPlan { int t1, k; };
+static RagPlan rag_plan(int64_t W, int grp) {
+    RagPlan p{0, 1};
+    if (toggles().no_ragged || grp <= 0 || W < 1024 + 16) return p;
+    const int64_t F = W / 1024;
+    if (F > 2) return p;   // measured (profiles/r03_ab_ragged_splitk.txt): beyond two whole rounds the tail is too small a share to pay for the slab pass
+    const int64_t t1 = (F * 1024 / grp) & ~7ll;   // whole groups of 8 position tiles (the kernel's id -> tile map deals them over the XCDs)
+    const int64_t E = W - t1 * grp;
+    if (t1 <= 0 || E <= 0 || E >= 512) return p;
+    p.t1 = (int)t1;
+    p.k = (int)((512 + E - 1) / E);
+    if (p.k > 16) p.k = 16;
+    return p;
+}
+
 // K splits for a gather launch of `blocks` workgroups over KIT 16-row steps: fill ~2 waves of
 // 256 CUs x 3 blocks, keep >= 8 steps per split (thin kernel: >= 16, its 4 waves split again).
 static int gather_splits(int blocks, int KIT, bool thin) {
@@ -2256,12 +2287,13 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
 #undef DCV_LAUNCH_DMA1
     DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s, %s> (%d x %d tile, %d class%s in one launch%s%s)",
                     tc.bn == 128 ? (tc.bm == 64 ? "2, 1, 2, 2" : "2, 2, 2, 2") : tc.bn == 64 ? (tc.bm == 128 ? "2, 1, 1, 4" : "2, 2, 1, 4") : "1, 2, 1, 4",
-                    ds ? "true" : "false", pt ? "true" : "false", bfm ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? ", split-K" : "",
+                    ds ? "true" : "false", pt ? "true" : "false", bfm ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? (pend.c[0].rag_m0 > 0 ? ", ragged split-K" : ", split-K") : "",
                     bfm ? ", bf16 products" : "");
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
-        for (int i = 0; i < n; ++i) tot = std::max<int64_t>(tot, (int64_t)OC * (pend.c[i].Mp / 4));
+        for (int i = 0; i < n; ++i) tot = std::max<int64_t>(tot, (int64_t)OC * (pend.c[i].slab_mp / 4));
+        if (tot == 0) return DCV_OK;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256), (unsigned)n), dim3(256), 0, stream, pend, KS);
         DCV_LAUNCH_CHECK();
     }
@@ -2284,15 +2316,37 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // much (a partial round of short workgroups) and fill an under-filled chip; measured on the 4x4 / 8x8-spatial
         // layers.  DCV_HALF_M = 0 / 1 forces the choice for A/B runs.
         int64_t W = 0;
+        int ncls0 = 0;
         for (const GatherClass& c : classes) {
             if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
             const int64_t Mc = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
             W += ((OC + tc.bn - 1) / tc.bn) * ((Mc + tc.bm - 1) / tc.bm);
+            ++ncls0;
         }
         const double rounds = (double)W / 1024.0, frac = rounds - (double)(int64_t)rounds;
         bool half = (rounds > 0.4 && rounds < 1.0) || (rounds >= 1.0 && rounds < 3.0 && frac > 0.15 && frac < 0.55);
         if (toggles().half_m >= 0) half = toggles().half_m != 0;
+        // a little more than a whole number of rounds: whole tiles with a K-split tail (below) rather than half tiles, where the tail qualifies
+        // (and every class still has the >= 384 workgroups below which gather_splits splits the whole op)
+        if (half && rounds >= 1.0 && toggles().half_m < 0 && !toggles().no_lds_dma && ncls0 > 0 && W / ncls0 >= 384 &&
+            rag_plan(W, ((OC + tc.bn - 1) / tc.bn) * ncls0).k > 1) half = false;
         if (half) tc.bm /= 2;
+    }
+    // ragged split-K plan of this op (LDS-DMA MFMA path only; decided per op because the classes share one launch)
+    RagPlan rag{0, 1};
+    if (tc.bn >= 64 && !toggles().no_lds_dma) {
+        int64_t W = 0;
+        int ncls = 0;
+        for (const GatherClass& c : classes) {
+            if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+            const int64_t Mc = (int64_t)yd.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+            W += ((OC + tc.bn - 1) / tc.bn) * ((Mc + tc.bm - 1) / tc.bm);
+            ++ncls;
+        }
+        rag = rag_plan(W, ((OC + tc.bn - 1) / tc.bn) * ncls);
+        // the fused BatchNorm partial sums come from the direct epilogue only: a split op makes the BN op read y once more,
+        // which is not worth it for the large activations (their tail is a few per cent of many rounds anyway)
+        if (stat != nullptr && (int64_t)OC * yd.n * yd.d * yd.h * yd.w * 4 > (160ll << 20)) rag.k = 1;
     }
     if (gate && tc.bn == 4) return fail(DCV_EUNSUPPORTED, "%s: the gated epilogue is not built into the thin (OC <= 4) kernels", tag);
     if (gate)   // a stride-parity class without taps (stride > kernel) has positions no workgroup visits: they would stay un-gated
@@ -2412,12 +2466,30 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         const int blocks = (OCp / tc.bn) * (Mp / tc.bm);
         // the classes of an op share one launch, so the grid to fill is all of them together (depth-step classes
         // skip a varying share of their steps and measured better with the per-class count)
-        const int KS = gather_splits(tc.bn != 4 && !dstep ? blocks * (int)classes.size() : blocks, KIT, tc.bn == 4);
+        int KS = gather_splits(tc.bn != 4 && !dstep ? blocks * (int)classes.size() : blocks, KIT, tc.bn == 4);
+        // ragged split-K (rag_plan): this class will take the LDS-DMA kernel (same conditions as the structured-walk choice below),
+        // the op is not split as a whole, and a part keeps at least 8 K steps
+        int rag_m0 = 0;
+        {
+            const int nd_ = c.taps[0].n, THW_ = c.taps[1].n * c.taps[2].n;
+            const int64_t sc4_ = xd.sc * 4;
+            const bool will_dma = tc.bn != 4 && !toggles().no_lds_dma &&
+                (dstep || (16 % T == 0 && RC % (16 / T) == 0 && sc4_ * (16 / T) < (1ll << 30)) ||
+                 (THW_ == 16 && (nd_ == 2 || nd_ == 4 || nd_ == 8) && c.taps[0].mul == 1 && c.taps[0].base == 0 &&
+                  c.taps[0].delta[nd_ - 1] == nd_ - 1 && c.o_ext[0] + nd_ - 1 <= c.taps[0].size && sc4_ < (1ll << 30)));
+            if (KS == 1 && rag.k > 1 && will_dma && KIT / rag.k >= 8) {
+                KS = rag.k;
+                rag_m0 = (int)std::min<int64_t>((int64_t)rag.t1 * tc.bm, Mp);
+            } else if (rag.k > 1 && KS == 1) {
+                rag.k = 1;   // one class cannot: none does (they share the launch's grid.y)
+            }
+        }
         const int kper = (KIT + KS - 1) / KS;
         const int KS2 = (KIT + kper - 1) / kper;
+        const int slab_mp = Mp - rag_m0;
         // ---- pack weights ----
         const size_t wp_bytes = align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
-        const size_t slab_bytes = KS2 > 1 ? align_up((size_t)KS2 * OCp * Mp * sizeof(float), 256) : 0;
+        const size_t slab_bytes = KS2 > 1 ? align_up(std::max<size_t>((size_t)KS2 * OCp * slab_mp * sizeof(float), 256), 256) : 0;
         float* wp;
         if (pk_base) {
             if (pk_off + wp_bytes > pack->bytes) return fail(DCV_EWORKSPACE, "%s: packed-weight buffer too small (%zu needed, %zu given)", tag, pk_off + wp_bytes, pack->bytes);
@@ -2492,9 +2564,11 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         a.slab = slab;
         a.kper = kper;
         a.Mp = Mp;
+        a.slab_mp = slab_mp;
+        a.rag_m0 = rag_m0;
         a.gate = gate;
         a.gate_slope = gate_slope;
-        a.stat = stat_ok ? stat : nullptr;
+        a.stat = stat_ok && KS2 == 1 ? stat : nullptr;
         a.stat_ntm = stat_ntm;
         a.stat_cls = stat_ci++;
         bool thin_struct = false;
@@ -2603,6 +2677,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         const bool dma = a.structured && tc.bn != 4 && !toggles().no_lds_dma;
         if (!dma || KS2 > 1) stat_ok = false;   // only the LDS-DMA kernel's direct epilogue produces the sums
+        if (rag_m0 > 0 && !dma) return fail(DCV_EINVAL, "%s: internal: ragged split-K planned for a class that does not take the LDS-DMA kernel", tag);
         if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
             int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
             if (rcp != DCV_OK) return rcp;
@@ -2770,7 +2845,31 @@ static size_t gather_ws_bytes(int RC, int OC, int N, const std::vector<GatherCla
         const int KS = gather_splits(blocks, KIT, tc.bn == 4);   // per-class count: an upper bound of run_gather's choice
         if (KS > 1) tot += align_up((size_t)KS * OCp * Mp * sizeof(float), 256);
     }
-    return tot + 256;
+    // ragged split-K slabs (rag_plan), for either position-tile size run_gather may pick: an upper bound of its choice
+    size_t rag_tot = 0;
+    if (tc.bn >= 64)
+        for (int bm : {tc.bm, tc.bm / 2}) {
+            int64_t W = 0;
+            int ncls = 0;
+            for (const GatherClass& c : classes) {
+                if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+                const int64_t Mc = (int64_t)N * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+                W += (OCp / tc.bn) * ((Mc + bm - 1) / bm);
+                ++ncls;
+            }
+            const RagPlan rp = rag_plan(W, (OCp / tc.bn) * ncls);
+            if (rp.k <= 1) continue;
+            size_t t = 0;
+            for (const GatherClass& c : classes) {
+                if (c.taps[0].n * c.taps[1].n * c.taps[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+                const int64_t Mc = (int64_t)N * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+                const int64_t Mp = (Mc + bm - 1) / bm * bm;
+                const int64_t m0 = std::min<int64_t>((int64_t)rp.t1 * bm, Mp);
+                t += align_up((size_t)rp.k * OCp * (size_t)(Mp - m0) * sizeof(float) + 256, 256);
+            }
+            rag_tot = std::max(rag_tot, t);
+        }
+    return tot + rag_tot + 256;
 }
 
 static size_t gather_pack_bytes(int RC, int OC, const std::vector<GatherClass>& classes) {
