@@ -551,6 +551,135 @@ struct BnBwdApply {
 };
 
 // ------------------------------------------------------------------------- //
+// Small BatchNorm layers, one launch per pass (round 3).  The 4x4 / 2x2 / 1x1-spatial layers of the generators and the
+// discriminators' trunks hold <= 32 K elements per channel: their passes are latency-bound ~5-25 us launches (statistics or
+// partials-finalize + apply forward; reduce + finalize + apply backward: 40 + 40 + 53 launches per iteration, ~3 ms of kernel
+// time).  Here ONE workgroup of 1024 threads owns a channel, keeps its elements in registers (<= 8 groups of 4 per thread and
+// tensor), reduces over the workgroup in a fixed order (fp32 per thread over <= 32 terms, fp64 across lanes and waves),
+// and applies — each tensor is read once and the pass is one launch.  Same expressions as the large-tensor kernels, so the
+// (Leaky)ReLU branch decided in the backward pass is the forward pass's.
+// ------------------------------------------------------------------------- //
+constexpr int SMALL_NT = 1024, SMALL_K = 8;
+
+__device__ __forceinline__ void block_sum_1024(double (&v)[2], double* red /* [16][2] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v[0] = wave_sum(v[0]); v[1] = wave_sum(v[1]);
+    __syncthreads();
+    if (lane == 0) { red[wave * 2] = v[0]; red[wave * 2 + 1] = v[1]; }
+    __syncthreads();
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < SMALL_NT / 64; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+    v[0] = a; v[1] = b;
+}
+
+__global__ __launch_bounds__(SMALL_NT) void bn_fwd_small_kernel(ChanMap m, const float* __restrict__ x, RowView xv, float* __restrict__ y, RowView yv,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                                float* __restrict__ save_mean, float* __restrict__ save_invstd, const float* __restrict__ mask,
+                                                                double count, float eps, float momentum, int act, float slope) {
+    __shared__ double red[2 * SMALL_NT / 64];
+    const int c = blockIdx.x;
+    float4 v[SMALL_K];
+    int32_t oy[SMALL_K];
+    float mk[SMALL_K];
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMALL_K; ++k) {
+        const int64_t g = (int64_t)threadIdx.x + (int64_t)k * SMALL_NT;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f); oy[k] = -1; mk[k] = 1.f;
+        if (g < m.per_chan) {
+            const Pos p = locate_c(m, c, (uint32_t)g);
+            v[k] = *reinterpret_cast<const float4*>(x + offs_c(m, xv, p));
+            oy[k] = (int32_t)offs_c(m, yv, p);
+            if (mask) mk[k] = mask[(int64_t)p.n * m.C + c];
+            a0 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+            a1 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+    }
+    double acc[2] = {(double)a0, (double)a1};
+    block_sum_1024(acc, red);
+    const double mean_d = acc[0] / count;
+    double var = acc[1] / count - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mu = (float)mean_d, is = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        if (c == 0 && nbt) *nbt += 1;
+        bn_finalize_channel(c, acc[0], acc[1], count, eps, momentum, save_mean, save_invstd, running_mean, running_var);
+    }
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;      // BnApply's expressions
+#pragma unroll
+    for (int k = 0; k < SMALL_K; ++k)
+        if (oy[k] >= 0) {
+            float4 o;
+            o.x = act_fwd((v[k].x * sc + sh) * mk[k], act, slope);
+            o.y = act_fwd((v[k].y * sc + sh) * mk[k], act, slope);
+            o.z = act_fwd((v[k].z * sc + sh) * mk[k], act, slope);
+            o.w = act_fwd((v[k].w * sc + sh) * mk[k], act, slope);
+            *reinterpret_cast<float4*>(y + oy[k]) = o;
+        }
+}
+
+__global__ __launch_bounds__(SMALL_NT) void bn_bwd_small_kernel(ChanMap m, const float* __restrict__ dy, RowView dyv, const float* __restrict__ x, RowView xv,
+                                                                float* __restrict__ dx, RowView dxv, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ mask,
+                                                                double count, int act, float slope, int training, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[2 * SMALL_NT / 64];
+    const int c = blockIdx.x;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    const float sc = ga * is, sh = be - mu * sc;                 // the forward pass's expression decides the activation's branch
+    float4 dz[SMALL_K], xh[SMALL_K];
+    int32_t od[SMALL_K];   // element offsets: these tensors are far below 2^31 elements (bn_small_ok)
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMALL_K; ++k) {
+        const int64_t g = (int64_t)threadIdx.x + (int64_t)k * SMALL_NT;
+        od[k] = -1;
+        dz[k] = make_float4(0.f, 0.f, 0.f, 0.f); xh[k] = dz[k];
+        if (g < m.per_chan) {
+            const Pos p = locate_c(m, c, (uint32_t)g);
+            const float4 v = *reinterpret_cast<const float4*>(x + offs_c(m, xv, p));
+            const float4 d = *reinterpret_cast<const float4*>(dy + offs_c(m, dyv, p));
+            od[k] = (int32_t)offs_c(m, dxv, p);
+            const float mk = mask ? mask[(int64_t)p.n * m.C + c] : 1.f;
+            const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+            float zz[4], hh[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hh[i] = (vv[i] - mu) * is;
+                const float z = (vv[i] * sc + sh) * mk;
+                float t = dd[i] * mk;
+                if (act == DCV_ACT_LEAKY) t *= (z > 0.f ? 1.f : slope);
+                else if (act == DCV_ACT_TANH) { const float th = tanhf(z); t *= 1.f - th * th; }
+                zz[i] = t;
+                a0 += t; a1 += t * hh[i];
+            }
+            dz[k] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+            xh[k] = make_float4(hh[0], hh[1], hh[2], hh[3]);
+        }
+    }
+    double acc[2] = {(double)a0, (double)a1};
+    block_sum_1024(acc, red);
+    if (threadIdx.x == 0) { dbeta[c] = (float)acc[0]; dgamma[c] = (float)acc[1]; }
+    const float k0 = training ? (float)(acc[0] / count) : 0.f, k1 = training ? (float)(acc[1] / count) : 0.f;   // bn_bwd_finalize_kernel's coef
+#pragma unroll
+    for (int k = 0; k < SMALL_K; ++k)
+        if (od[k] >= 0) {
+            float4 o;
+            o.x = ga * is * (dz[k].x - k0 - xh[k].x * k1);
+            o.y = ga * is * (dz[k].y - k0 - xh[k].y * k1);
+            o.z = ga * is * (dz[k].z - k0 - xh[k].z * k1);
+            o.w = ga * is * (dz[k].w - k0 - xh[k].w * k1);
+            *reinterpret_cast<float4*>(dx + od[k]) = o;
+        }
+}
+
+static bool bn_small_ok(const RowMap& m, const ChanMap& cm) {
+    static const bool off = getenv("DCV_NO_BN_SMALL") != nullptr;
+    return !off && m.vec == 4 && m.inner != 1 && cm.per_chan <= (int64_t)SMALL_NT * SMALL_K && cm.per_chan >= 64 && m.C >= 32 && m.groups < (1ll << 28);
+}
+
+// ------------------------------------------------------------------------- //
 // GAN loss: one block, value + gradient
 // ------------------------------------------------------------------------- //
 __global__ __launch_bounds__(256) void gan_loss_kernel(const float* __restrict__ y, int64_t n, int kind, float* __restrict__ loss_out, int accumulate, float* __restrict__ dy) {
@@ -1044,6 +1173,13 @@ int dcv_bn_act_forward(const float* x, const dcv_dims5* xd, float* y, const dcv_
     if (training) {
         if (ws_bytes < dcv_bn_workspace_bytes(C) || !ws) return fail(DCV_EWORKSPACE, "bn_act_forward: workspace too small");
         ChanMap cm = make_chanmap(m);
+        if (bn_small_ok(m, cm)) {
+            const double cnt = (double)xd->n * xd->d * xd->h * xd->w;
+            hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(C), dim3(SMALL_NT), 0, s, cm, x, rv(*xd), y, rv(*yd), gamma, beta, running_mean, running_var, num_batches_tracked,
+                               save_mean, save_invstd, mask, cnt, eps, momentum, act, slope);
+            DCV_LAUNCH_CHECK();
+            return DCV_OK;
+        }
         double* partial = static_cast<double*>(ws);
         if (m.vec == 4) hipLaunchKernelGGL((bn_stats_kernel<4>), dim3(C * cm.split), dim3(256), 0, s, cm, x, rv(*xd), partial);
         else hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(C * cm.split), dim3(256), 0, s, cm, x, rv(*xd), partial);
@@ -1074,6 +1210,15 @@ int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, cons
     if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
     (void)ws; (void)ws_bytes;
     const double count = (double)xd->n * xd->d * xd->h * xd->w;
+    {
+        const ChanMap cm = make_chanmap(m);
+        if (bn_small_ok(m, cm)) {   // the channel fits one workgroup's registers: its own sums are as cheap as combining the conv's partials, and it is one launch
+            hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(C), dim3(SMALL_NT), 0, s, cm, x, rv(*xd), y, rv(*yd), gamma, beta, running_mean, running_var, num_batches_tracked,
+                               save_mean, save_invstd, mask, count, eps, momentum, act, slope);
+            DCV_LAUNCH_CHECK();
+            return DCV_OK;
+        }
+    }
     hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3(C), dim3(256), 0, s, stat, nparts, pitch, count, eps, momentum, save_mean, save_invstd, running_mean, running_var,
                        num_batches_tracked);
     DCV_LAUNCH_CHECK();
@@ -1094,6 +1239,13 @@ int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, c
     RowMap m = make_rowmap(*xd, views, 3, ptrs);
     if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
     ChanMap cm = make_chanmap(m);
+    if (bn_small_ok(m, cm)) {
+        const double cnt = (double)xd->n * xd->d * xd->h * xd->w;
+        hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(C), dim3(SMALL_NT), 0, s, cm, dy, rv(*dyd), x, rv(*xd), dx, rv(*dxd), gamma, beta, save_mean, save_invstd, mask,
+                           cnt, act, slope, training, dgamma, dbeta);
+        DCV_LAUNCH_CHECK();
+        return DCV_OK;
+    }
     double* partial = static_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)(2048 + C) * 2 * sizeof(double) * 2);
     if (m.vec == 4 && m.inner != 1 && m.gpr % 256 == 0 && !ew_rows_off())
