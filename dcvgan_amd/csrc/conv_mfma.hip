@@ -674,6 +674,11 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     }
     const int wstep4 = 16 * a.OCp * 4;
 
+#ifdef DCV_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long q_a = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // DSTEP: depth tap of step `it` is ud = nd-1 - (it & (nd-1)) (ascending addresses); its validity bit
     // for this lane's position is bit ud of vmask; an invalid tap turns every voffset of the step into padding
     const int ndm1 = (1 << a.s_log2p) - 1;
@@ -694,6 +699,11 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         __syncthreads();
     }
 #define DCV_STEP_LIVE(IT) ((dmask >> (ndm1 - ((IT) & ndm1))) & 1u)
+#ifdef DCV_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long q_b = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 
     // The host pass type-checks builtins without gfx950 target features and rejects the 16-byte
     // LDS-DMA size, which silently drops the kernel's host stub: device pass only.
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         if (bid_ < 4096) {                                                                                   \
             unsigned long long* g = g_stamp[bid_][wave];                                                     \
             const unsigned long long q_end = clock64();                                                      \
-            g[0] = q_pro - q_start; g[1] = q_wait; g[2] = q_loop; g[3] = (q_end - q_epi) | ((q_epi - q_fw) << 32); g[4] = q_end - q_start; g[5] = (unsigned long long)nst; \
+            g[0] = q_pro - q_start; g[1] = q_wait; g[2] = q_loop; g[3] = (q_end - q_epi) | ((q_epi - q_fw) << 32); g[4] = q_end - q_start; g[5] = (unsigned long long)nst | ((q_a - q_start) << 16) | ((q_b - q_a) << 40); \
         }                                                                                                    \
     }
 #else

@@ -39,10 +39,14 @@ for name in sys.argv[1:] or ["vdis.5"]:
     buf = np.zeros((4096, 4, 6), dtype=np.uint64)
     L.dcv_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), 4096)
     fw = (buf[..., 3] >> np.uint64(32)).astype(np.float64); buf[..., 3] &= np.uint64(0xffffffff)
+    pa = ((buf[..., 5] >> np.uint64(16)) & np.uint64(0xffffff)).astype(np.float64); pb = (buf[..., 5] >> np.uint64(40)).astype(np.float64); buf[..., 5] &= np.uint64(0xffff)
     b = buf.astype(np.float64)
     nb = int((b[:, 0, 5] > 0).sum())
     s = b[:nb]
     n = s[..., 5].mean()
+    late = slice(1024, nb) if nb > 1200 else slice(0, nb)
+    print(name, "prologue split, workgroups that start beside running ones: index arithmetic %.0f | depth-mask OR + barriers %.0f | accumulators, first tile issue %.0f cycles" % (
+        pa[:nb][late].mean(), pb[:nb][late].mean(), (s[..., 0] - pa[:nb] - pb[:nb])[late].mean()))
     pro = s[..., 0].mean(axis=1)
     print(name, "prologue cycles by block id: <1024: %.0f   1024-2047: %.0f   >=2048: %.0f | percentiles 10/50/90: %s" % (
         pro[:1024].mean(), pro[1024:2048].mean() if nb > 1024 else 0, pro[2048:].mean() if nb > 2048 else 0, np.percentile(pro, [10, 50, 90]).round()))
