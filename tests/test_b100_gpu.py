@@ -114,7 +114,7 @@ def test_batch_split_identity_b100(dev, name):
     from dcvgan_amd.configs import CONFIGS
     from dcvgan_amd.rng import InjectedRng
     from oracle import dcvgan_oracle as O
-    from oracle.stepcheck import ReplayRng64
+    from oracle.stepcheck import KINK_EPS, KINK_FRAC, ReplayRng64
     from tests import fullwidth as FW
     cfg = CONFIGS[name]
     assert cfg.batchsize == B
@@ -194,9 +194,9 @@ def test_batch_split_identity_b100(dev, name):
     differing = sum(int((a != b).sum()) for a, b in zip(k16, kB))
     for tag, grads, kinks in (("B=100", grB, kB), ("B=16", gr16, k16)):
         oxg, oxc, oys, ogr, (flips, total, far) = oracle64(kinks)
-        assert flips <= max(8, 2e-6 * total) and far <= 5e-5, (tag, flips, total, far)
+        assert flips <= max(8, KINK_FRAC * total) and far <= KINK_EPS, (tag, flips, total, far)
         assert rel(xgB if tag == "B=100" else xg16, oxg) < 1e-5 and rel(xcB if tag == "B=100" else xc16, oxc) < 1e-5
         worst = max((rel(grads[key], gref), key) for key, gref in ogr.items())
-        assert worst[0] < 5e-5, (tag, worst, differing)
+        assert worst[0] < 1e-4, (tag, worst, differing)
         assert len(ogr) == 83          # every parameter tensor of the five models
     assert differing <= 64, differing
