@@ -104,7 +104,7 @@ def test_fullwidth_b2_against_reference_and_fp64(dev, fixture):
         assert G.relerr(FW.gsub(gh), fx[f"gradsub/{n}/{k}"]) < 3e-2, (n, k)
 
 
-@pytest.mark.parametrize("name,B", [("isogd-depth", 2), ("surreal-depth1", 2), ("isogd-flow", 2), ("isogd-depth", 8), ("debug-isogd-depth", 2)])
+@pytest.mark.parametrize("name,B", [("isogd-depth", 2), ("surreal-depth1", 2), ("isogd-flow", 2), ("isogd-depth", 8), ("surreal-depth1", 8), ("isogd-flow", 8), ("debug-isogd-depth", 2)])
 def test_fullwidth_discriminator_phase(dev, name, B):
     """The OTHER backward of an iteration (trainer.py:285-319): the discriminator losses on a real and a fake batch, backpropagated
     through the discriminators (no data gradient into the real inputs, parameter gradients accumulated over both batches) and — the
