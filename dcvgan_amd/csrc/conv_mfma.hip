@@ -1739,10 +1739,17 @@ __device__ __forceinline__ void wgrad_tile_addr(const WgradArgs& a, int m, int m
 }
 
 // TD = dense-operand row tiles per wave: 2 -> 128 x 128 tile, 1 -> 64 x 128 (64-channel layers: cgen.down0, gdis.5)
-template <int TD, bool BF = false>
+// D16 (round 3): the dense operand's rows — contiguous, 16-byte aligned runs of positions — are staged by 16-byte LDS-DMAs, FOUR rows per
+// instruction (lanes 16 i .. 16 i + 15 fetch row i) instead of one row per dword DMA: DR / 4 dense DMAs per wave and tile instead of DR (40 instead
+// of 64 DMAs per 128 x 128 tile, 36 instead of 48 for the 64-row tile).  An LDS-DMA lands lane-linear, so the four rows of an instruction sit at a
+// pitch of 64 words — the same banks; lane (row i, granule q) therefore fetches granule q ^ i of its row (an XOR swizzle on the global side),
+// and row groups are 272 words apart: a fragment read "32 rows x one position" then has a 2-way bank conflict at worst (16 B granules leave 16 of the
+// 64 banks per word phase), which costs ~2 cycles against the 64 of the MFMA it feeds.
+template <int TD, bool BF = false, bool D16 = false>
 __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
-    constexpr int BD = 64 * TD, BJ = 128, P = 65, TILE = (BD + BJ) * P, DR = 16 * TD;   // DR: dense rows DMA'd per wave
-    __shared__ float smem[2 * TILE];
+    static_assert(!(BF && D16), "the 16-byte dense staging is built for the fp32 form");
+    constexpr int BD = 64 * TD, BJ = 128, P = 65, GP = 272, DREG = D16 ? (BD / 4) * GP : BD * P, TILE = DREG + BJ * P, DR = 16 * TD;   // DR: dense rows DMA'd per wave
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1784,19 +1791,35 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     // row I (0..31) of this wave's dense / gathered share of the tile in buffer BUF
 #define DCV_WG_DROW(BUF, I) \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(smem + (BUF) * TILE + (wave * DR + (I)) * P), 4, dvo, dso0 + (I) * a.d_sc4, 0, 0);
+    // D16: rows 4 Q .. 4 Q + 3 of this wave's dense share in one instruction (dvo holds the lane's swizzled granule + row offset)
+#define DCV_WG_DGRP(BUF, Q) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(smem + (BUF) * TILE + (wave * (DR / 4) + (Q)) * GP), 16, dvo, dso0 + 4 * (Q) * a.d_sc4, 0, 0);
 #define DCV_WG_GROW(BUF, I) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void*)(smem + (BUF) * TILE + (BD + wave * 32 + (I)) * P), 4, gvo[(I) & 15], ((I) < 16 ? gso0 : gso1), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void*)(smem + (BUF) * TILE + DREG + (wave * 32 + (I)) * P), 4, gvo[(I) & 15], ((I) < 16 ? gso0 : gso1), 0, 0);
 #else
 #define DCV_WG_DROW(BUF, I) { (void)dso0; }
+#define DCV_WG_DGRP(BUF, Q) { (void)dso0; }
 #define DCV_WG_GROW(BUF, I) { (void)gso0; (void)gso1; }
 #endif
+    // D16: lane (i = lane / 16, q = lane % 16) stages granule q ^ i of row i of every 4-row group: its voffset is the dword form's voffset of
+    // position 4 (q ^ i) of the tile (a cross-lane read; M, the chunk and the row length are multiples of 4 and rows are 16-byte aligned —
+    // checked on the host — so a granule is valid or padding as a whole) plus i channel strides
+    const int d16_src = 4 * (4 * ((lane & 15) ^ (lane >> 4)));          // ds_bpermute byte address of the source lane
+    const uint32_t d16_row = (uint32_t)(lane >> 4) * (uint32_t)a.d_sc4;
+#define DCV_WG_D16(DVO) if constexpr (D16) { DVO = (uint32_t)__builtin_amdgcn_ds_bpermute(d16_src, (int)(DVO)); DVO = (DVO & 0x80000000u) ? 0x80000000u : DVO + d16_row; }
 
     const int l31 = lane & 31, lhi = lane >> 5;
     if (nit > 0) {
         DCV_WG_ADDR(0, dvo, gvo)
+        DCV_WG_D16(dvo)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { if (i < DR) { DCV_WG_DROW(0, i < DR ? i : 0) } DCV_WG_GROW(0, i) }
+        for (int i = 0; i < 32; ++i) {
+            if constexpr (D16) { if (i < DR / 4) { DCV_WG_DGRP(0, i < DR / 4 ? i : 0) } }
+            else { if (i < DR) { DCV_WG_DROW(0, i < DR ? i : 0) } }
+            DCV_WG_GROW(0, i)
+        }
         DCV_WG_ADDR(min(1, nit - 1), dvo, gvo)   // voffsets of the tile whose DMAs the first loop step issues
+        DCV_WG_D16(dvo)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1809,11 +1832,23 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         STAMP(w0);
         // dvo / gvo hold tile min(it + 1, nit - 1) (last tile: a harmless repeat into the idle buffer)
         const float* da = smem + buf * TILE + ((wd * TD) * 32 + l31) * P + lhi;
-        const float* gb = smem + buf * TILE + (BD + (wj * 2) * 32 + l31) * P + lhi;
+        const float* gb = smem + buf * TILE + DREG + ((wj * 2) * 32 + l31) * P + lhi;
+        // D16: row r = (wd TD + i) 32 + l31 lives in group r / 4 at row slot r % 4 = l31 % 4; position p = 2 ks + lhi of it at word
+        // (((p >> 2) ^ (l31 & 3)) << 2) | (p & 3): one base per value of (ks >> 1) & 3, everything else is an immediate
+        const float* dq[4];
+        if constexpr (D16) {
+#pragma unroll
+            for (int lo = 0; lo < 4; ++lo)
+                dq[lo] = smem + buf * TILE + ((wd * TD) * 8 + (l31 >> 2)) * GP + (l31 & 3) * 64 + ((lo ^ (l31 & 3)) << 2) + lhi;
+        } else {
+            dq[0] = dq[1] = dq[2] = dq[3] = da;
+        }
+#define DCV_WG_AF(I, KS) (D16 ? dq[((KS) >> 1) & 3][(I) * 8 * GP + (((KS) >> 1) & ~3) * 4 + 2 * ((KS) & 1)] : da[(I) * 32 * P + 2 * (KS)])
         __builtin_amdgcn_s_setprio(2);
         // voffsets of the tile after next: plain VALU work with no consumer inside this step, free to be
         // scheduled into the shadow of the MFMAs below (one wave per SIMD: nothing else would hide it)
         DCV_WG_ADDR(min(it + 2, nit - 1), dvon, gvon)
+        DCV_WG_D16(dvon)
         if constexpr (BF) {
             // bf16 products: the tile's 64 positions are 4 MFMA k-blocks of 16; a lane of half-wave lhi holds positions
             // 16 s + 8 lhi .. + 7 of its channel row.  The next tile's DR + 32 row DMAs go out first.
@@ -1850,13 +1885,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
         } else {
         float af[2][TD], bf[2][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { if (i < TD) af[0][i < TD ? i : 0] = da[i * 32 * P]; bf[0][i] = gb[i * 32 * P]; }
+        for (int i = 0; i < 2; ++i) { if (i < TD) af[0][i < TD ? i : 0] = DCV_WG_AF(i, 0); bf[0][i] = gb[i * 32 * P]; }
 #pragma unroll
         for (int ks = 0; ks < 32; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < 32) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { if (i < TD) af[nxt][i < TD ? i : 0] = da[i * 32 * P + 2 * (ks + 1)]; bf[nxt][i] = gb[i * 32 * P + 2 * (ks + 1)]; }
+                for (int i = 0; i < 2; ++i) { if (i < TD) af[nxt][i < TD ? i : 0] = DCV_WG_AF(i, ks + 1); bf[nxt][i] = gb[i * 32 * P + 2 * (ks + 1)]; }
             }
 #pragma unroll
             for (int i = 0; i < TD; ++i)
@@ -1865,6 +1900,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             // next tile's DR + 32 row DMAs, three per k-step (dense rows first interleaved with gathered ones): the last
             // one is issued about ten k-steps (2500 cycles) before the wait at the end of the tile
+            if constexpr (D16) {
+                // DR / 4 + 32 DMAs: two per k-step (the dense groups first, each followed by a gathered row), the last one ~12 k-steps before the wait
+#pragma unroll
+                for (int q = 2 * ks; q < 2 * ks + 2; ++q)
+                    if (q < DR / 4 + 32) {
+                        if (q < DR / 2) {
+                            if (q & 1) { DCV_WG_GROW(buf ^ 1, q >> 1) } else { DCV_WG_DGRP(buf ^ 1, (q >> 1) < DR / 4 ? (q >> 1) : 0) }
+                        } else {
+                            DCV_WG_GROW(buf ^ 1, (q - DR / 4) < 32 ? (q - DR / 4) : 0)
+                        }
+                    }
+            } else {
 #pragma unroll
             for (int q = 3 * ks; q < 3 * ks + 3; ++q)
                 if (q < DR + 32) {
@@ -1874,11 +1921,31 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
                         DCV_WG_GROW(buf ^ 1, (q - DR) < 32 ? (q - DR) : 0)
                     }
                 }
+            }
             // issue order of a k-step: every MFMA is followed by a share of the step's other instructions — the wave issues in order
             // and an MFMA occupies the matrix pipe for 64 cycles, so whatever follows ONE MFMA issues in its shadow for free, while
             // the step's 2 + TD fragment reads and 3 row DMAs (~90 issue cycles) all behind the LAST MFMA overran its shadow by ~25
             // cycles (8810 -> 8582 cycles per 128-MFMA tile, 8192 being the matrix pipe's own time)
-            {
+            if constexpr (D16) {
+                constexpr int NI = DR / 4 + 32;
+                const int left = NI - 2 * ks < 0 ? 0 : (NI - 2 * ks > 2 ? 2 : NI - 2 * ks);
+                if constexpr (TD == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (left >= 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (left == 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    if (left >= 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (left == 2) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+            } else {
                 constexpr int NI = DR + 32;
                 const int left = NI - 3 * ks < 0 ? 0 : (NI - 3 * ks > 3 ? 3 : NI - 3 * ks);
                 if constexpr (TD == 2) {
@@ -2147,13 +2214,14 @@ static std::map<std::string, DevTable> g_tables;   // keys start with the device
 struct Toggles {
     bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64, no_quad, no_thin_wgrad;
     int half_m;
-    bool no_ragged;
+    bool no_ragged, no_wgrad_d16;
     Toggles() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
         no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD"); no_thin_wgrad = on("DCV_NO_THIN_WGRAD");
         half_m = getenv("DCV_HALF_M") ? atoi(getenv("DCV_HALF_M")) : -1;
         no_ragged = on("DCV_NO_RAGGED");
+        no_wgrad_d16 = on("DCV_NO_WGRAD_D16");
     }
 };
 static const Toggles& toggles() {
@@ -3167,14 +3235,22 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
             a.hw_sel[t] = (1u << (8 + uh)) | (1u << (16 + uw));
         }
     }
+    // 16-byte staging of the dense operand (wgrad_dma_kernel<.., D16>): its rows are contiguous, 16-byte aligned runs of positions, and tiles, chunks
+    // and M are whole granules of 4 positions
+    // ... and only the 64-row tile takes it: its 48 row DMAs per 64 MFMAs are what bounds it (cgen.down0 1.351 -> 1.286 ms, gdis.5 0.355 -> 0.353), while
+    // the MFMA-bound 128 x 128 tile measured 4-6 % SLOWER with it (the 2-way conflicts of the swizzled fragment reads; profiles/r03_ab_wgrad_d16.txt)
+    const bool d16 = !toggles().no_wgrad_d16 && tc.bd == 64 && dd.sw == 1 && dd.w % 4 == 0 && dd.sh % 4 == 0 && dd.sd % 4 == 0 && dd.sn % 4 == 0 && dd.sc % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && g_precision.load(std::memory_order_relaxed) != 1;
     {
         const bool wbf = g_precision.load(std::memory_order_relaxed) == 1;
-        if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf ? "true" : "false", tc.bd, tc.bj, S2, wbf ? ", bf16 products" : "");
+        if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %s, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf ? "true" : "false", d16 ? "true" : "false", tc.bd, tc.bj, S2, wbf ? ", bf16 products" : "");
         else DCV_NOTE_KERNEL("wgrad_gemm_kernel (%d x %d tile, %d slabs)", tc.bd, tc.bj, S2);
     }
     if (dma && a.log2nd >= 0 && g_precision.load(std::memory_order_relaxed) == 1) {
         if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((wgrad_dma_kernel<1, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
+    } else if (dma && a.log2nd >= 0 && d16) {
+        hipLaunchKernelGGL((wgrad_dma_kernel<1, false, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
     } else if (dma && a.log2nd >= 0) {
         if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, false>), dim3(tiles, S2), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((wgrad_dma_kernel<1, false>), dim3(tiles, S2), dim3(256), 0, stream, a);
