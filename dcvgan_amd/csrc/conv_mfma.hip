@@ -546,7 +546,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     unsigned long long q_wait = 0, q_loop = 0;
 #endif
     constexpr int XPT = 16 * BM / 256;
-    constexpr int WF4 = 16 * BN / 4;
+    // W tile of a K step in 16-byte granules: fp32 [16][BN] floats; bf16 products: packed bf16 [2][BN][8] (PackArgs.fmt 1), half the bytes
+    constexpr int WF4 = BF ? 2 * BN : 16 * BN / 4;
     constexpr int WPT = (WF4 + 255) / 256;
     static_assert(WOC * WM == 4, "4 waves");
     // ONE LDS array: [2][16][BM] X tiles then [2][16][BN] W tiles
@@ -669,10 +670,14 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
         const int f = tid + 256 * j;
-        const int row = f / (BN / 4), c4 = f % (BN / 4);
-        wvo[j] = (uint32_t)(4 * (row * a.OCp + oc0 + c4 * 4));
+        if constexpr (BF) {   // granule f = (k block f / BN, output channel f % BN)
+            wvo[j] = (uint32_t)(16 * ((f / BN) * a.OCp + oc0 + f % BN));
+        } else {
+            const int row = f / (BN / 4), c4 = f % (BN / 4);
+            wvo[j] = (uint32_t)(4 * (row * a.OCp + oc0 + c4 * 4));
+        }
     }
-    const int wstep4 = 16 * a.OCp * 4;
+    const int wstep4 = BF ? 2 * a.OCp * 16 : 16 * a.OCp * 4;
 
 #ifdef DCV_STAMP
     __builtin_amdgcn_sched_barrier(0);
@@ -785,12 +790,8 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
             for (int i = 0; i < (PATCH ? NS : XPT); ++i) DCV_ISSUE_X(itn, soffn, buf ^ 1, i)
             bf16x8 a8[TOC], b8[TM];
 #pragma unroll
-            for (int i = 0; i < TOC; ++i) {
-                float t[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) t[q] = wt[(8 * lhi + q) * BN + (woc * TOC + i) * 32 + l31];
-                a8[i] = pack_bf16x8(t);
-            }
+            for (int i = 0; i < TOC; ++i)   // packed bf16 weights: k rows 8 lhi .. 8 lhi + 7 of output channel row l31 are ONE 16-byte LDS read
+                a8[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(wt) + 16 * (lhi * BN + (woc * TOC + i) * 32 + l31));
 #pragma unroll
             for (int jj = 0; jj < TM; ++jj) {
                 float t[8];
@@ -1485,6 +1486,7 @@ struct PackArgs {
     const KEntry* ktab[4];
     float* wp[4];
     int32_t K16[4];
+    int32_t fmt[4];   // 0: fp32 wp[k][OCp]; 1: bf16 wp16[k / 8][OCp][8] (the bf16-product LDS-DMA kernels: an MFMA A fragment is one 16-byte LDS read)
 };
 __global__ void pack_weights_kernel(const float* __restrict__ w, const PackArgs pa, int OC, int OCp, int64_t ws_o) {
     const int c = blockIdx.y;
@@ -1494,7 +1496,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const PackArgs 
     const KEntry e = pa.ktab[c][k];
     float v = 0.f;
     if (oc < OC && !(e.tapsel >> 31)) v = w[(int64_t)oc * ws_o + e.w_off];
-    pa.wp[c][i] = v;
+    if (pa.fmt[c]) reinterpret_cast<__bf16*>(pa.wp[c])[((int64_t)(k >> 3) * OCp + oc) * 8 + (k & 7)] = (__bf16)v;   // RNE, as v_cvt_pk_bf16_f32 in the activations' fragments
+    else pa.wp[c][i] = v;
 }
 
 // --------------------------------------------------------------------------- //
@@ -2549,10 +2552,11 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // ragged split-K (rag_plan): this class will take the LDS-DMA kernel (same conditions as the structured-walk choice below),
         // the op is not split as a whole, and a part keeps at least 8 K steps
         int rag_m0 = 0;
+        bool will_dma = false;
         {
             const int nd_ = c.taps[0].n, THW_ = c.taps[1].n * c.taps[2].n;
             const int64_t sc4_ = xd.sc * 4;
-            const bool will_dma = tc.bn != 4 && !toggles().no_lds_dma &&
+            will_dma = tc.bn != 4 && !toggles().no_lds_dma &&
                 (dstep || (16 % T == 0 && RC % (16 / T) == 0 && sc4_ * (16 / T) < (1ll << 30)) ||
                  (THW_ == 16 && (nd_ == 2 || nd_ == 4 || nd_ == 8) && c.taps[0].mul == 1 && c.taps[0].base == 0 &&
                   c.taps[0].delta[nd_ - 1] == nd_ - 1 && c.o_ext[0] + nd_ - 1 <= c.taps[0].size && sc4_ < (1ll << 30)));
@@ -2586,6 +2590,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             packs.ktab[npack] = tab.dev;
             packs.wp[npack] = wp;
             packs.K16[npack] = KIT * 16;
+            packs.fmt[npack] = (will_dma && g_precision.load(std::memory_order_relaxed) == 1) ? 1 : 0;
             if (KIT * 16 > packmax) packmax = KIT * 16;
             ++npack;
         }
@@ -2756,7 +2761,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         const bool dma = a.structured && tc.bn != 4 && !toggles().no_lds_dma;
         if (!dma || KS2 > 1) stat_ok = false;   // only the LDS-DMA kernel's direct epilogue produces the sums
-        if (rag_m0 > 0 && !dma) return fail(DCV_EINVAL, "%s: internal: ragged split-K planned for a class that does not take the LDS-DMA kernel", tag);
+        if ((rag_m0 > 0 || will_dma) && !dma) return fail(DCV_EINVAL, "%s: internal: the LDS-DMA kernel was planned for a class that does not take it", tag);
         if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
             int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
             if (rcp != DCV_OK) return rcp;

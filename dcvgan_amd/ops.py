@@ -112,7 +112,7 @@ class _PackCache:
     def get(self, w, which, g, xd_t, yd_t, xd, yd):
         key = (which, g.key(), tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
         e = self.entries.get(key)
-        stamp = (w._version, w.data_ptr())
+        stamp = (w._version, w.data_ptr(), lib().dcv_get_precision())     # the bf16-product kernels read a bf16-packed copy
         if _POISON:
             # debug builds of the tests: edits autograd cannot see (`p.data.normal_()`, raw-pointer writes) do not bump the version;
             # a checksum of the live weights in the stamp turns "silently convolving with stale packed weights" into a repack
