@@ -104,7 +104,12 @@ def test_conv_fwd_bwd(dev, case, strided):
     assert rel(gw, gw_ref) < TOL
 
 
-@pytest.mark.parametrize("case", [c for c in CONVS if c[0] in ("conv2d_4s2p1", "conv2d_4s2p1_wide", "conv2d_4s2p1_32_oc40", "conv2d_4s2p1_32_oc130",
+# a size at which the ragged split-K of the LDS-DMA kernel triggers (4 classes x 270 position tiles = 1080 workgroups: one round of 1024 + 56): the tiles before the
+# split point accumulate / gate in the GEMM epilogue, the split tail in splitk_reduce_kernel — both must honour the slice already holding a gradient
+RAGGED_CASE = ("conv2d_4s2p1_ragged_tail", False, 2, 128, 512, 4, 2, 1, (16, 16), 540)
+
+
+@pytest.mark.parametrize("case", [RAGGED_CASE] + [c for c in CONVS if c[0] in ("conv2d_4s2p1", "conv2d_4s2p1_wide", "conv2d_4s2p1_32_oc40", "conv2d_4s2p1_32_oc130",
                                                                 "conv2d_4s2p1_8_oc72", "conv2d_3s1p1", "conv3d_4s122_16_oc70", "convT2d_4s2p1_16_oc36", "conv2d_4s2p1_stem2")],
                          ids=lambda c: c[0])
 def test_conv_backward_data_accumulates_into_a_slice(dev, case):
@@ -134,6 +139,9 @@ def test_conv_backward_data_accumulates_into_a_slice(dev, case):
     need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(dxd), C.byref(dyd), 1)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     N.check(L.dcv_conv_backward_data(C.byref(geom), ptr(dy_d), C.byref(dyd), ptr(w_d), ptr(dx), C.byref(dxd), 1, None, ptr(ws), need, stream_ptr()), "accumulate")
+    if name.endswith("ragged_tail"):
+        L.dcv_debug_last_kernel.restype = C.c_char_p
+        assert "ragged split-K" in L.dcv_debug_last_kernel().decode(), L.dcv_debug_last_kernel().decode()
     assert rel(wide_d, want) < 1e-5
     assert torch.equal(wide_d[:, :5].cpu(), wide[:, :5])          # the neighbouring channels are untouched
     # dcv_conv_backward_data_gated: the same, then times the LeakyReLU derivative read off the conv's own input, which
