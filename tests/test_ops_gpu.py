@@ -385,6 +385,36 @@ def test_conv_bn_fused_statistics(dev):
     assert nfused >= 1
 
 
+def test_conv_bn_when_the_conv_splits_its_tail(dev):
+    """A conv -> BatchNorm pair whose convolution runs the ragged split-K (550 position tiles x 2 channel tiles = 1100 workgroups: one round + 76): the
+    tail's outputs come out of splitk_reduce_kernel, the epilogue's fused BatchNorm sums are not produced (nparts = 0) and the BN op takes its own statistics —
+    against torch on the host: output, running statistics and all four gradients."""
+    import ctypes as C
+    from dcvgan_amd import native as N, ops
+    g = torch.Generator().manual_seed(21)
+    n, cin, cout = 1100, 128, 256
+    w0 = torch.randn(cout, cin, 4, 4, generator=g) * 0.05
+    x0 = torch.randn(n, cin, 16, 16, generator=g)
+    gamma0 = torch.rand(cout, generator=g) + 0.5; beta0 = torch.randn(cout, generator=g) * 0.1
+    x, w, gamma, beta = (t.to(dev).requires_grad_(True) for t in (x0, w0, gamma0, beta0))
+    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    box = []
+    y = ops.conv(x, w, ops.conv_geom(w, (2, 2), (1, 1), False), bn_stats=box)
+    L = N.lib(); L.dcv_debug_last_kernel.restype = C.c_char_p
+    assert "ragged split-K" in L.dcv_debug_last_kernel().decode(), L.dcv_debug_last_kernel().decode()
+    assert box == []                                             # no fused sums from a split convolution
+    z = ops.bn_act(y, gamma, beta, rm, rv, True, ops.ACT_NONE, 0.0)    # no activation: with 18 M elements behind a 2048-term sum a (Leaky)ReLU adds ~5e-4 of branch lottery to dx
+    cot = torch.cos(torch.arange(z.numel(), dtype=torch.float32) * 0.37).view(z.shape)
+    gr = torch.autograd.grad((z * cot.to(dev)).sum(), [x, w, gamma, beta])
+    xr, wr, gar, ber = (t.clone().requires_grad_(True) for t in (x0, w0, gamma0, beta0))
+    rm_r, rv_r = torch.zeros(cout), torch.ones(cout)
+    z_ref = F.batch_norm(F.conv2d(xr, wr, None, 2, 1), rm_r, rv_r, gar, ber, True, 0.1, 1e-5)
+    gr_ref = torch.autograd.grad((z_ref * cot).sum(), [xr, wr, gar, ber])
+    assert rel(z, z_ref) < 1e-5 and rel(rm, rm_r) < 1e-5 and rel(rv, rv_r) < 1e-5
+    for a, b in zip(gr, gr_ref):
+        assert rel(a, b) < 1e-4
+
+
 def test_thin_wgrad_ragged_slabs(dev):
     """thin_wgrad3_kernel walks `pps` images per slab; 1025 images in slabs of 2 leave a last slab of one image."""
     import ctypes as C
