@@ -46,6 +46,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // (v_mfma_f32_32x32x16_bf16): tensors, weights, statistics and accumulators stay fp32 in HBM and LDS, the MFMA fragments
 // are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as they are read from LDS.  Throughput-only mode (BASELINE configs[2], [4]).
 std::atomic<int> g_precision{0};
+// per-call override from dcv_conv_geom.mfma (1 = fp32, 2 = bf16; 0 = the process default above), valid while a dcv_conv_* entry point runs on this thread
+static thread_local int t_precision = -1;
+static inline int eff_precision() { return t_precision >= 0 ? t_precision : g_precision.load(std::memory_order_relaxed); }
+struct PrecisionScope {
+    int saved;
+    explicit PrecisionScope(const dcv_conv_geom* g) : saved(t_precision) { if (g && g->mfma > 0) t_precision = g->mfma - 1; }
+    ~PrecisionScope() { t_precision = saved; }
+};
 
 // four v_cvt_pk_bf16_f32 (pairs converted as 2-vectors and laid side by side as dwords; element-wise conversion made the compiler
 // convert some values singly and merge them with v_perm / v_alignbit: 80 conversions + 64 merges per 64-position tile of the
@@ -2348,7 +2356,7 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
         pend.c[0].pad0 = n;
     }
     const bool ds = pend.c[0].structured == 2, pt = pend.c[0].patch != 0;
-    const bool bfm = g_precision.load(std::memory_order_relaxed) == 1;
+    const bool bfm = eff_precision() == 1;
 #define DCV_LAUNCH_DMA1(A, B, C_, D, BF_)                                                                                     \
     {                                                                                                                         \
         if (ds && pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, true, BF_>), grid, dim3(256), 0, stream, pend); \
@@ -2590,7 +2598,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             packs.ktab[npack] = tab.dev;
             packs.wp[npack] = wp;
             packs.K16[npack] = KIT * 16;
-            packs.fmt[npack] = (will_dma && g_precision.load(std::memory_order_relaxed) == 1) ? 1 : 0;
+            packs.fmt[npack] = (will_dma && eff_precision() == 1) ? 1 : 0;
             if (KIT * 16 > packmax) packmax = KIT * 16;
             ++npack;
         }
@@ -3245,13 +3253,13 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     // ... and only the 64-row tile takes it: its 48 row DMAs per 64 MFMAs are what bounds it (cgen.down0 1.351 -> 1.286 ms, gdis.5 0.355 -> 0.353), while
     // the MFMA-bound 128 x 128 tile measured 4-6 % SLOWER with it (the 2-way conflicts of the swizzled fragment reads; profiles/r03_ab_wgrad_d16.txt)
     const bool d16 = !toggles().no_wgrad_d16 && tc.bd == 64 && dd.sw == 1 && dd.w % 4 == 0 && dd.sh % 4 == 0 && dd.sd % 4 == 0 && dd.sn % 4 == 0 && dd.sc % 4 == 0 &&
-                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && g_precision.load(std::memory_order_relaxed) != 1;
+                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && eff_precision() != 1;
     {
-        const bool wbf = g_precision.load(std::memory_order_relaxed) == 1;
+        const bool wbf = eff_precision() == 1;
         if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %s, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf ? "true" : "false", d16 ? "true" : "false", tc.bd, tc.bj, S2, wbf ? ", bf16 products" : "");
         else DCV_NOTE_KERNEL("wgrad_gemm_kernel (%d x %d tile, %d slabs)", tc.bd, tc.bj, S2);
     }
-    if (dma && a.log2nd >= 0 && g_precision.load(std::memory_order_relaxed) == 1) {
+    if (dma && a.log2nd >= 0 && eff_precision() == 1) {
         if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((wgrad_dma_kernel<1, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
     } else if (dma && a.log2nd >= 0 && d16) {
@@ -3396,6 +3404,8 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
                          float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr,
                          const dcv_wpack* pack = nullptr, size_t* pack_need = nullptr, const float* gate = nullptr, float gate_slope = 0.f) {
     // xd = module input dims, yd = module output dims, always.
+    if (g && (g->mfma < 0 || g->mfma > 2)) return fail(DCV_EINVAL, "conv: dcv_conv_geom.mfma must be 0 (process default), 1 (fp32) or 2 (bf16 products)");
+    PrecisionScope prec_scope(g);
     {
         dcv_conv_geom g2;
         dcv_dims5 y2;
@@ -3531,6 +3541,8 @@ int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const 
 
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd,
                              float* dw, void* ws, size_t ws_bytes, void* stream) {
+    if (g && (g->mfma < 0 || g->mfma > 2)) return fail(DCV_EINVAL, "conv_bwd_weight: dcv_conv_geom.mfma must be 0, 1 or 2");
+    PrecisionScope prec_scope(g);
     {
         dcv_conv_geom g2;
         dcv_dims5 y2;

@@ -52,7 +52,7 @@ def geom_of(conv) -> "ops.ConvGeom":
         raise NotImplementedError("dilation/groups are not used by DCVGAN")
     if isinstance(conv, nn.ConvTranspose2d) and any(o != 0 for o in conv.output_padding):
         raise NotImplementedError("output_padding is not used by DCVGAN")
-    return ops.conv_geom(conv.weight, conv.stride, conv.padding, isinstance(conv, nn.ConvTranspose2d))
+    return ops.conv_geom(conv.weight, conv.stride, conv.padding, isinstance(conv, nn.ConvTranspose2d), getattr(conv, "_dcv_precision", None))
 
 
 def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, partials=None):

@@ -39,7 +39,8 @@ class ConvGeom(C.Structure):
     _fields_ = [("kd", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
                 ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
-                ("transposed", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32)]
+                ("transposed", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("mfma", C.c_int32)]     # 0 = process default, 1 = fp32, 2 = bf16 products (per-module switch)
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)
@@ -120,8 +121,12 @@ def check(rc: int, what: str):
         raise NativeError(f"{what} failed (code {rc}): {lib().dcv_last_error().decode(errors='replace')}")
 
 
+PRECISION_CODE = {None: 0, "default": 0, "fp32": 1, "bf16": 2}
+
+
 def set_precision(mode: str):
-    """'fp32' (default) or 'bf16': bf16 MFMA products with fp32 accumulation in the large GEMM kernels (throughput mode)."""
+    """PROCESS DEFAULT — 'fp32' or 'bf16': bf16 MFMA products with fp32 accumulation in the large GEMM kernels (throughput mode).
+    Modules can override it one by one: dcvgan_amd.util.set_precision(module, "bf16" | "fp32" | None)."""
     check(lib().dcv_set_precision({"fp32": 0, "bf16": 1}[mode]), "dcv_set_precision")
 
 

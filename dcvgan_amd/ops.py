@@ -45,15 +45,15 @@ def _ws(tag: str, nbytes: int, device) -> Tuple[C.c_void_p, int]:
 # --------------------------------------------------------------------------- #
 # convolution
 # --------------------------------------------------------------------------- #
-def conv_geom(weight: torch.Tensor, stride, padding, transposed: bool) -> ConvGeom:
-    """Geometry from a torch weight: (Cout,Cin,k..) or, transposed, (Cin,Cout,k..)."""
+def conv_geom(weight: torch.Tensor, stride, padding, transposed: bool, precision=None) -> ConvGeom:
+    """Geometry from a torch weight: (Cout,Cin,k..) or, transposed, (Cin,Cout,k..).  `precision`: None (process default), "fp32" or "bf16"."""
     k = list(weight.shape[2:])
     s, p = list(stride), list(padding)
     if len(k) == 2:
         k, s, p = [1] + k, [1] + s, [0] + p
     a, b = weight.shape[0], weight.shape[1]
     cin, cout = (a, b) if transposed else (b, a)
-    return ConvGeom(k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], int(transposed), cin, cout)
+    return ConvGeom(k[0], k[1], k[2], s[0], s[1], s[2], p[0], p[1], p[2], int(transposed), cin, cout, N.PRECISION_CODE[precision])
 
 
 def _out_shape(g: ConvGeom, x: torch.Tensor):
@@ -112,7 +112,7 @@ class _PackCache:
     def get(self, w, which, g, xd_t, yd_t, xd, yd):
         key = (which, g.key(), tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
         e = self.entries.get(key)
-        stamp = (w._version, w.data_ptr(), lib().dcv_get_precision())     # the bf16-product kernels read a bf16-packed copy
+        stamp = (w._version, w.data_ptr(), g.mfma or 1 + lib().dcv_get_precision())     # the bf16-product kernels read a bf16-packed copy
         if _POISON:
             # debug builds of the tests: edits autograd cannot see (`p.data.normal_()`, raw-pointer writes) do not bump the version;
             # a checksum of the live weights in the stamp turns "silently convolving with stale packed weights" into a repack

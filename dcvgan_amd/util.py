@@ -25,3 +25,20 @@ def init_weights(layer) -> None:
     elif kind is nn.BatchNorm2d:
         nn.init.normal_(layer.weight.data, 1.0, 0.02)
         nn.init.constant_(layer.bias.data, 0.0)
+
+
+def set_precision(module, mode=None):
+    """Per-module switch of the MFMA product precision (the reference is fp32-only; this is the build's throughput option for BASELINE's bf16 / fp16
+    configs): "bf16" = bf16 products with fp32 accumulation in this module's convolutions (forward, data and weight gradients), "fp32", or None = follow
+    the process default (`dcvgan_amd.native.set_precision`).  Everything else of the module — tensors in HBM, BatchNorm statistics, optimiser — stays fp32."""
+    import torch.nn as nn
+    if mode not in (None, "fp32", "bf16"):
+        raise ValueError(f"precision {mode!r}: expected None, 'fp32' or 'bf16'")
+    for m in module.modules():
+        if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)):
+            if mode is None:
+                if hasattr(m, "_dcv_precision"):
+                    del m._dcv_precision
+            else:
+                m._dcv_precision = mode
+    return module

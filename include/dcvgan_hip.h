@@ -56,6 +56,9 @@ typedef struct dcv_conv_geom {
     int32_t pd, ph, pw;
     int32_t transposed;
     int32_t cin, cout;
+    /* precision of the MFMA products for THIS module's three passes: 0 = the process default (dcv_set_precision), 1 = fp32, 2 = bf16 products
+     * (round 3: a per-module switch; dcvgan_amd.util.set_precision(module, "bf16") sets it on a module's convolutions) */
+    int32_t mfma;
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
@@ -63,7 +66,7 @@ int dcv_version(void);
 /* number of kernel launches issued through this library so far (tests use it to
  * prove the HIP path, not a fallback, did the work) */
 uint64_t dcv_launch_count(void);
-/* Precision of the MFMA products in the large GEMM kernels (process-wide): 0 = fp32 (default; the mode every parity claim
+/* DEFAULT precision of the MFMA products in the large GEMM kernels, for modules whose dcv_conv_geom.mfma is 0: 0 = fp32 (default; the mode every parity claim
  * and the headline benchmark refer to), 1 = bf16 products with fp32 accumulation (v_mfma_f32_32x32x16_bf16): tensors,
  * weights, BatchNorm statistics and optimiser state stay fp32, only the MFMA fragments are rounded (RNE) as they are read
  * from LDS.  A throughput mode for BASELINE.json's bf16 / fp16 configs; the reference itself is fp32-only. */

@@ -97,3 +97,45 @@ def test_training_iteration_in_bf16_mode(bf16, name):
     assert all(v == v and abs(v) < 100 for v in out.values()), out
     after = torch.cat([p.detach().reshape(-1) for p in models["cgen"].parameters()])
     assert float((after != before).float().mean()) > 0.9
+
+
+def test_precision_is_a_per_module_switch():
+    """dcv_conv_geom.mfma / util.set_precision(module, ...): one module's convolutions run bf16 products while the process default stays fp32 — and a module pinned to
+    "fp32" stays fp32 under a bf16 process default.  The kernel instance names say which ran; the packed-weight cache keeps the two formats apart."""
+    from dcvgan_amd import layers, native, ops, util
+    native.lib()
+    dev = torch.device("cuda:0")
+    assert native.lib().dcv_get_precision() == 0
+    last = lambda: native.lib().dcv_debug_last_kernel().decode()
+    g = torch.Generator().manual_seed(3)
+    a = torch.nn.Conv2d(16, 128, 4, 2, 1, bias=False).to(dev); b = torch.nn.Conv2d(16, 128, 4, 2, 1, bias=False).to(dev)
+    with torch.no_grad():
+        b.weight.copy_(a.weight)
+    x = torch.randn(9, 16, 16, 16, generator=g).to(dev)
+    util.set_precision(a, "bf16")
+    assert layers.geom_of(a).mfma == 2 and layers.geom_of(b).mfma == 0
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    ya = ops.conv(xa, a.weight, layers.geom_of(a)); ka = last()
+    yb = ops.conv(xb, b.weight, layers.geom_of(b)); kb = last()
+    assert "bf16" in ka and "bf16" not in kb, (ka, kb)
+    e = rel(ya, yb)
+    assert 2e-4 < e < 1e-2, e                                   # same weights and input: the two results differ by bf16 rounding, no more
+    cot = torch.randn(ya.shape, generator=g).to(dev)
+    ga = torch.autograd.grad((ya * cot).sum(), [xa, a.weight])
+    gb = torch.autograd.grad((yb * cot).sum(), [xb, b.weight])
+    # data and weight gradients follow the module's switch too (they run on autograd's thread, whose kernel-name record this thread cannot read: the
+    # bf16 rounding of their results is the evidence — the fp32 instances would agree to ~1e-7)
+    assert 2e-4 < rel(ga[0], gb[0]) < 1e-2 and 2e-4 < rel(ga[1], gb[1]) < 1e-2
+    # the other way round: process default bf16, module pinned to fp32
+    native.set_precision("bf16")
+    try:
+        util.set_precision(a, "fp32")
+        with torch.no_grad():
+            y1 = ops.conv(x, a.weight, layers.geom_of(a)); k1 = last()
+            y2 = ops.conv(x, b.weight, layers.geom_of(b)); k2 = last()
+        assert "bf16" not in k1 and "bf16" in k2, (k1, k2)
+        assert rel(y1, yb) < 1e-6                                # the pinned module reproduces the fp32 result (its fp32 pack was not confused with the bf16 one)
+        util.set_precision(a, None)
+        assert layers.geom_of(a).mfma == 0
+    finally:
+        native.set_precision("fp32")
