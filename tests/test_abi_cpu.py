@@ -56,6 +56,12 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 0) == 48 * 32 * 4
     assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 1) > 0
     assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 2) == 0
+    # the per-module precision field: 0 (process default), 1 (fp32), 2 (bf16 products); anything else is refused on the host
+    assert ctypes.sizeof(ConvGeom) == 13 * 4 and [f for f, _ in ConvGeom._fields_][-1] == "mfma"
+    g_bad = ConvGeom(1, 4, 4, 1, 2, 2, 0, 1, 1, 0, 3, 8, 3)
+    assert lib.dcv_conv_workspace_bytes(ctypes.byref(g_bad), ctypes.byref(x), ctypes.byref(y_ok), 0) == 0 and b"mfma" in lib.dcv_last_error()
+    g_bf = ConvGeom(1, 4, 4, 1, 2, 2, 0, 1, 1, 0, 3, 8, 2)
+    assert lib.dcv_conv_workspace_bytes(ctypes.byref(g_bf), ctypes.byref(x), ctypes.byref(y_ok), 0) > 0
 
 
 def test_product_path_has_no_cpu_fallback(lib):
