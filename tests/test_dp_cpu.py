@@ -117,6 +117,9 @@ def test_bench_launcher_fails_loudly_without_gpus():
     import subprocess
     import sys
     import time
+    import pytest
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: the ranks would run (tests/test_dp_gpu.py covers that form)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
