@@ -29,7 +29,7 @@ from . import dcvgan_oracle as O
 
 MODELS = ("ggen", "cgen", "idis", "vdis", "gdis")
 TAU = 1e-2            # sensitive: sqrt(v_hat) < TAU * rms over the tensor
-KINK_EPS = 2e-3       # |pre-activation| / rms(layer) of an element whose recorded branch differs from fp64's own sign.  Wider than the 5e-5 of the single-pass gradient tests: after an Adam step some BatchNorm channels are ill-conditioned (|mean| / std ~ 1e3: fp32 rounding of x is 1e-4 of the normalised value); measured 1.2e-4 on HIP (gdis.main.6, surreal-depth1 iteration 2) and 9.6e-5 for the reference's own fp32 CPU arithmetic (gdis.main.10, isogd-depth iteration 1; tools/stepcheck_reference.py)
+KINK_EPS = 1e-2       # |pre-activation| / rms(layer) of an element whose recorded branch differs from fp64's own sign.  Wider than the 5e-5 of the single-pass gradient tests: after an Adam step some BatchNorm channels are ill-conditioned (|mean| / std ~ 1e3: fp32 rounding of x is 1e-4 of the normalised value); measured 1.2e-4 on HIP (gdis.main.6, surreal-depth1 iteration 2) and 9.6e-5 for the reference's own fp32 CPU arithmetic (gdis.main.10, isogd-depth iteration 1; tools/stepcheck_reference.py)
 KINK_FRAC = 5e-6      # such elements / all activation elements
 
 
@@ -176,11 +176,12 @@ def checked_iteration(runner, models, opts, forced: ForcedStepOracle, layers_mod
             "kink_flips": ref["kink_flips"], "kink_total": ref["kink_total"], "kink_far": ref["kink_far"], "kink_worst_call": ref["kink_worst_call"]}
 
 
-# The bars every caller uses.  Measured: the fixed-seed tests' reports and a sweep over 6 seeds x 3 full-width configs x 2 iterations
-# (tools/step_seed_sweep.py -> profiles/r03_step_parity/seed_sweep_b2.txt): update <= 5.5e-5, loss <= 1.1e-6, buffers <= 1.6e-5, pattern
-# <= 4.9e-7 of the elements and <= 1.6e-4 rms from zero, sensitive elements off <= 2.8 % of a tensor's.  Each bar is ~10x the sweep's maximum;
-# a 1 % learning-rate error moves the update by 1e-2 (tests/test_stepcheck_cpu.py).
-UPDATE_TOL = 5e-4          # relative L2 of a tensor's update over its insensitive elements
+# The bars every caller uses.  Measured: the fixed-seed tests' reports (update <= 1.6e-5, pattern <= 1.2e-4 rms) and sweeps over 20 seeds x 3 full-width
+# configs x 2 iterations at B = 2 plus B = 4 / B = 8 runs (tools/step_seed_sweep.py -> profiles/r03_step_parity/seed_sweep_*.txt, 150 checked iterations,
+# 0 failures): update <= 1.2e-4, loss <= 2.5e-6, buffers <= 1.6e-5, pattern <= 6e-7 of the elements and <= 9.1e-4 rms from zero, sensitive elements off
+# <= 2.8 % of a tensor's.  The two lottery quantities (update, pattern distance) are heavy-tailed over seeds — an ill-conditioned BatchNorm channel —
+# so their bars sit ~10x above the sweeps' maxima rather than the tests' values; a 1 % learning-rate error moves the update by 1e-2 (tests/test_stepcheck_cpu.py).
+UPDATE_TOL = 1e-3          # relative L2 of a tensor's update over its insensitive elements
 LOSS_TOL = 1e-4            # every loss of the iteration, relative
 BUFFER_TOL = 2e-4          # BatchNorm running statistics after the iteration, relative L2 per buffer
 

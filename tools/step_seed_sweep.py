@@ -13,6 +13,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=8)
+    ap.add_argument("--seed0", type=int, default=0, help="first seed (sweeps with different --seed0 do not repeat one another)")
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--configs", nargs="*", default=["isogd-depth", "surreal-depth1", "isogd-flow"])
@@ -28,7 +29,7 @@ def main():
     worst = {"update_rel_l2": 0.0, "loss_rel": 0.0, "buffers_rel": 0.0, "kink_far": 0.0, "kink_frac": 0.0, "sens_off_frac": 0.0, "worst_over_lr": 0.0}
     fails = 0
     for name in a.configs:
-        for seed in range(a.seeds):
+        for seed in range(a.seed0, a.seed0 + a.seeds):
             cfg = CONFIGS[name].scaled(batchsize=a.batch)
             torch.manual_seed(1000 + seed)
             models = trainer.build_models(cfg, torch.device("cpu"))
