@@ -53,14 +53,54 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the DP path on one GPU)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6"],
                     help="bf16: MFMA products in bf16 with fp32 accumulation in the large GEMM kernels (tensors, weights, statistics and "
-                         "optimiser state stay fp32) — a secondary throughput line for BASELINE configs[2]/[4], not the headline")
+                         "optimiser state stay fp32) — a secondary throughput line for BASELINE configs[2]/[4], not the headline.  "
+                         "f32x6 (experimental): fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulation")
+    ap.add_argument("--no-as-trainer", action="store_true", help="skip the secondary `as_trainer` key: the same iteration driven the way the reference's "
+                                                                 "trainer.py drives it (4 host syncs on the losses, :326-328,363; a fresh pinned host batch "
+                                                                 ".to(device) per iteration, :293-297), timed AFTER the headline region")
     ap.add_argument("--minimal", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-minimal", action="store_true", help="skip the secondary `minimal_schedule` key (the schedule with the dead D-phase generator backward elided, "
                                                               "timed AFTER the headline region) — profile runs use this so that the trace holds the as-written schedule only")
     ap.add_argument("--cpus", type=int, default=0, help="pin this rank to K host CPUs (host-headroom probe: 8 ranks on a 16-CPU share have 2 each)")
     return ap.parse_args()
+
+
+def gpu_numa_cpus(local_rank, local_world):
+    """CPUs of the NUMA node GPU `local_rank` hangs off, this rank's share of them.  AMD GPUs under /sys/class/drm (vendor 0x1002) in PCI
+    bus order — HIP's default enumeration order — filtered through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are plain index
+    lists.  None when anything is missing (containers often hide sysfs): the rank then keeps the affinity it was started with."""
+    import glob
+    try:
+        gpus = []
+        for d in glob.glob("/sys/class/drm/renderD*/device"):
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
+                continue
+            gpus.append((os.path.basename(os.path.realpath(d)), int(open(os.path.join(d, "numa_node")).read())))
+        gpus.sort()
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+            v = os.environ.get(var)
+            if v and all(x.strip().isdigit() for x in v.split(",")):
+                gpus = [gpus[int(x)] for x in v.split(",")]
+        if local_rank >= len(gpus):
+            return None
+        node = gpus[local_rank][1]
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        cpus = sorted(set(cpus) & os.sched_getaffinity(0))
+        peers = [r for r in range(local_world) if r < len(gpus) and gpus[r][1] == node]      # ranks whose GPU shares this node split its CPUs
+        if not cpus or local_rank not in peers:
+            return None
+        share = max(1, len(cpus) // len(peers))
+        i = peers.index(local_rank)
+        return cpus[i * share:(i + 1) * share] or None
+    except Exception:
+        return None
 
 
 def spawn_ranks(a):
@@ -150,20 +190,47 @@ def dominant_kernel_probe(models, cfg, dev):
 def committed_traffic(batch, kernel):
     """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (tools/round_profile.sh ->
     tools/dominant_pmc.py; FETCH_SIZE doubled for the 16-byte-per-lane operand streams as the MI355X guide prescribes).  PMC counters
-    cannot be collected from inside this process, so the figure is only reported when the profile was taken at THIS batch size from the
-    kernel instance this run just launched (`dcv_debug_last_kernel`); otherwise null — a stale number is worse than none."""
+    cannot be collected from inside this process, so the figure is only reported when the profile was taken from THIS SOURCE — the sha256
+    of dcvgan_amd/csrc (native.csrc_digest) stored in the profile equals the working tree's — at THIS batch size from the kernel instance
+    this run just launched (`dcv_debug_last_kernel`); otherwise null — a stale number is worse than none."""
     import glob
+    from dcvgan_amd import native
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dominant_kernel_pmc.json")), reverse=True):
         try:
             t = json.load(open(f))
         except Exception:
             continue
         inst = lambda k: k.split(" (")[0].replace(" ", "")      # template instance without the library's "(tile, classes)" annotation
+        if t.get("csrc_sha256") != native.csrc_digest():
+            return None, {"note": f"profiles/{os.path.basename(f)} was taken from other kernel sources (csrc_sha256 {str(t.get('csrc_sha256'))[:12]} at git head "
+                                  f"{t.get('git_head')}, this build {native.csrc_digest()[:12]}): not reported"}
         if int(t.get("batch", -1)) == int(batch) and inst(t.get("kernel", "")) == inst(kernel):
             return t["hbm_bytes_per_launch"], {"algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"], "unit": "bytes per launch",
                                                "traffic_over_algorithmic": t.get("traffic_over_algorithmic"), "profiled_at_git_head": t.get("git_head"),
                                                "source": f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)"}
         return None, {"note": f"profiles/{os.path.basename(f)} was taken from kernel {t.get('kernel')!r} at batch {t.get('batch')}; this run launched {kernel!r} at batch {batch}"}
+    return None, None
+
+
+def committed_step_traffic(config, batch):
+    """HBM bytes per ITERATION from the newest committed whole-step PMC passes (tools/pmc_step.sh), under the same rule: same source digest,
+    same config and batch, else null.  FETCH_SIZE doubled as the guide prescribes for 16-byte-per-lane streams (every large read of the step
+    is one: LDS-DMA granules, 16-byte elementwise groups); the raw sum is given beside it."""
+    import glob
+    from dcvgan_amd import native
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_summary.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        meta = t.get("__meta__") or {}
+        if meta.get("csrc_sha256") != native.csrc_digest() or meta.get("config") != config or int(meta.get("batch", -1)) != int(batch):
+            return None, {"note": f"profiles/{os.path.basename(f)}: taken from other sources / config / batch ({meta or 'no metadata'}): not reported"}
+        steps = max(1, int(meta.get("steps", 1)))
+        fe = sum(v.get("FETCH_SIZE", 0.0) for k, v in t.items() if k != "__meta__") * 1024 / steps
+        wr = sum(v.get("WRITE_SIZE", 0.0) for k, v in t.items() if k != "__meta__") * 1024 / steps
+        return 2 * fe + wr, {"unit": "bytes per iteration", "fetch_size_bytes_raw": fe, "write_size_bytes": wr, "profiled_at_git_head": meta.get("git_head"),
+                             "source": f"profiles/{os.path.basename(f)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)"}
     return None, None
 
 
@@ -218,9 +285,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    numa_cpus = None
     if a.cpus:
         mine = sorted(os.sched_getaffinity(0))
         os.sched_setaffinity(0, set(mine[(rank * a.cpus) % len(mine):][:a.cpus]) or set(mine[:a.cpus]))
+    elif world > 1 and not a.all_ranks_on_device0:
+        # every rank (spawned by us or by torch.distributed.run) enqueues ~900 launches per iteration from one Python thread: keep that thread
+        # and its allocator on the NUMA node its GPU hangs off (before HIP is initialised, so the runtime's own threads inherit the mask)
+        numa_cpus = gpu_numa_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        if numa_cpus:
+            os.sched_setaffinity(0, set(numa_cpus))
     torch.set_num_threads(max(1, host_threads() // max(1, world)))    # N ranks share the host's CPU quota
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     if a.all_ranks_on_device0:
@@ -288,7 +362,7 @@ def main():
     losses = {k: float(v) for k, v in out.items()}
     assert all(x == x and abs(x) < 1e4 for x in losses.values()), losses
 
-    # secondary, clearly labelled and off by default: identical parameter updates, the dead D-phase generator backward elided
+    # secondary, clearly labelled, timed AFTER the headline region (--no-minimal skips it): identical parameter updates, the dead D-phase generator backward elided
     minimal = None
     if not a.no_minimal:
         runner2 = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=False, elide_dead_backward=True)
@@ -301,6 +375,28 @@ def main():
                    "value": B * world / (dt2 / a.steps), "unit": "videos/s", "ms_per_step": dt2 / a.steps * 1e3,
                    "flops_per_video_step": f_min, "frac": f_min * (B / (dt2 / a.steps)) / 1e12 / peak}
 
+    # secondary: the iteration as the reference's trainer.py drives it — the three D losses and the G loss are read on the host with
+    # .cpu().item() where trainer.py:326-328,363 read them, and every iteration starts from a fresh pinned host batch .to(device)
+    # (trainer.py:293-297; the DataLoader there pins memory, train.py:101-109).  The headline above stays the HBM-resident, sync-free figure.
+    as_trainer = None
+    if not a.no_as_trainer:
+        runner3 = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=True)
+        runner3.iteration = runner.iteration
+        pin = [(xc.cpu().pin_memory(), xg.cpu().pin_memory()) for _ in range(2)]      # a loader's double buffer
+
+        class _AsTrainer:
+            def step(self, _xc, _xg, t):
+                hc, hg = pin[runner3.iteration & 1]
+                return runner3.step(hc.to(dev, non_blocking=True), hg.to(dev, non_blocking=True), t)
+        at = _AsTrainer()
+        at.step(None, None, 0)
+        dt3, _ = timed(at, a.steps, 1)
+        as_trainer = {"note": "NOT the headline: sync_losses=True (four .cpu().item() host reads per iteration where trainer.py:326-328,363 has them) + a fresh "
+                              "pinned host batch copied to the device every iteration (trainer.py:293-297)",
+                      "value": B * world / (dt3 / a.steps), "unit": "videos/s", "ms_per_step": dt3 / a.steps * 1e3,
+                      "slower_than_headline_pct": (dt3 / dt - 1.0) * 100.0,
+                      "h2d_mb_per_step": (xc.numel() + xg.numel()) * 4 / 1e6}
+
     if rank == 0:
         per_step = dt / a.steps
         vps = B * world / per_step
@@ -309,6 +405,7 @@ def main():
         probe = dominant_kernel_probe(models, cfg, dev)
         gb_step = ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION * B
         traffic, traffic_detail = committed_traffic(B, probe["kernel"]) if a.precision == "fp32" else (None, None)
+        step_traffic, step_traffic_detail = committed_step_traffic(a.config, B) if a.precision == "fp32" else (None, None)
         gating = "" if cfg.num_gen_update == 1 else f", D update every {cfg.num_gen_update} iterations (FLOPs averaged over the cycle)"
         line = {
             "metric": "videos/sec per G+D step, 16x64x64 RGB+depth" if cfg.channel == 1 else "videos/sec per G+D step, 16x64x64 RGB+flow",
@@ -317,17 +414,23 @@ def main():
             "config": {"workload": f"config/{a.config}.yml G+D iteration (trainer.py:279-363), as-written schedule, "
                                    + ("fp32" if a.precision == "fp32" else "bf16 MFMA products / fp32 accumulation, storage, statistics and optimiser (throughput mode)") + gating,
                        "per_gpu_batch": B, "global_batch": B * world, "clip": f"16x64x64 RGB + {cfg.channel}-channel {cfg.geometric_info}",
-                       "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup)},
-            "roofline": {"bound": "mfma", "achieved": probe["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": probe["tflops"] / peak, "traffic": traffic, "traffic_detail": traffic_detail,
-                         "definition": "achieved / frac = the DOMINANT KERNEL timed alone (rounds 2+; round 1's BENCH line carried the whole-step figure "
-                                       "here — compare rounds on roofline.step.frac, which has been the same quantity throughout)",
-                         "kernel": probe,
+                       "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup),
+                       "rank0_cpus": sorted(os.sched_getaffinity(0)) if len(os.sched_getaffinity(0)) <= 64 else len(os.sched_getaffinity(0)),
+                       "rank0_cpus_from_gpu_numa_node": bool(numa_cpus)},
+            "roofline": {"bound": "mfma", "achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
+                         "frac": step_tflops / peak, "traffic": step_traffic, "traffic_detail": step_traffic_detail,
+                         "definition": "round 4 on: achieved / frac = the WHOLE ITERATION (conv / convT / GRU FLOPs of the as-written schedule x videos/s against the "
+                                       "dense MFMA peak of the precision in use) — the same quantity as round 1's roofline.frac and rounds 2-3's roofline.step.frac; "
+                                       "the dominant kernel timed alone (rounds 2-3's roofline.frac) is roofline.dominant_kernel; traffic = HBM bytes per ITERATION "
+                                       "from the committed PMC passes of this very source (else null), dominant_kernel.traffic = per launch of that kernel",
+                         "flops_per_video_step": f_step,
+                         "dominant_kernel": dict(probe, achieved=probe["tflops"], frac=probe["tflops"] / peak, traffic=traffic, traffic_detail=traffic_detail),
                          "step": {"achieved": step_tflops, "frac": step_tflops / peak, "flops_per_video_step": f_step},
                          "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,
                                  "frac": gb_step / per_step / PEAK_HBM_GBPS}},
             "cpu_baseline": cpu,
             "minimal_schedule": minimal,
+            "as_trainer": as_trainer,
             "losses_last_step": losses,
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
         }

@@ -2393,6 +2393,20 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
 // The generic driver: reduce over `RC` channels of tensor `x` (dims xd) into `OC`
 // channels of tensor `y` (dims yd); classes describe position/tap relations;
 // weight element (oc, rc, kd, kh, kw) lives at oc*ws_o + rc*ws_r + ((kd*KH)+kh)*KW+kw.
+// Which structured K walk (index-table-free, LDS-DMA kernel) a class of a gather op takes: 0 none (table-driven register staging),
+// 2 depth-step order, 1 every step covers 16/T whole channels with all T taps, 3 4x4 inner taps with step = (channel, un-padded depth tap).
+// Decided HERE ONLY: the ragged split-K plan, the packed-weight format and the launch setup all read this one answer.
+static int structured_walk(const GatherClass& c, const dcv_dims5& xd, int RC, bool dstep, bool thin) {
+    if (thin) return 0;
+    if (dstep) return 2;
+    const int nd = c.taps[0].n, THW = c.taps[1].n * c.taps[2].n, T = nd * THW;
+    const int64_t sc4 = xd.sc * 4;
+    if (T > 0 && 16 % T == 0 && RC % (16 / T) == 0 && sc4 * (16 / T) < (1ll << 30)) return 1;
+    if (THW == 16 && (nd == 2 || nd == 4 || nd == 8) && c.taps[0].mul == 1 && c.taps[0].base == 0 &&
+        c.taps[0].delta[nd - 1] == nd - 1 && c.o_ext[0] + nd - 1 <= c.taps[0].size && sc4 < (1ll << 30)) return 3;
+    return 0;
+}
+
 static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_dims5& yd, const float* w,
                       int RC, int OC, int64_t ws_o, int64_t ws_r, int KH, int KW,
                       const std::vector<GatherClass>& classes, int act, float slope, int accumulate,
@@ -2560,20 +2574,15 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // ragged split-K (rag_plan): this class will take the LDS-DMA kernel (same conditions as the structured-walk choice below),
         // the op is not split as a whole, and a part keeps at least 8 K steps
         int rag_m0 = 0;
-        bool will_dma = false;
-        {
-            const int nd_ = c.taps[0].n, THW_ = c.taps[1].n * c.taps[2].n;
-            const int64_t sc4_ = xd.sc * 4;
-            will_dma = tc.bn != 4 && !toggles().no_lds_dma &&
-                (dstep || (16 % T == 0 && RC % (16 / T) == 0 && sc4_ * (16 / T) < (1ll << 30)) ||
-                 (THW_ == 16 && (nd_ == 2 || nd_ == 4 || nd_ == 8) && c.taps[0].mul == 1 && c.taps[0].base == 0 &&
-                  c.taps[0].delta[nd_ - 1] == nd_ - 1 && c.o_ext[0] + nd_ - 1 <= c.taps[0].size && sc4_ < (1ll << 30)));
-            if (KS == 1 && rag.k > 1 && will_dma && KIT / rag.k >= 8) {
-                KS = rag.k;
-                rag_m0 = (int)std::min<int64_t>((int64_t)rag.t1 * tc.bm, Mp);
-            } else if (rag.k > 1 && KS == 1) {
-                rag.k = 1;   // one class cannot: none does (they share the launch's grid.y)
-            }
+        const int walk = structured_walk(c, xd, RC, dstep, tc.bn == 4);
+        const bool will_dma = walk != 0 && !toggles().no_lds_dma;   // (the toggle keeps the structured walk for the register-staged kernel)
+        if (KS == 1 && rag.k > 1 && will_dma && KIT / rag.k >= 8) {
+            KS = rag.k;
+            rag_m0 = (int)std::min<int64_t>((int64_t)rag.t1 * tc.bm, Mp);
+        } else if (rag.k > 1 && KS == 1) {
+            // this class cannot take the ragged split: the classes after it do not either.  Classes already planned keep theirs — the
+            // pending-launch logic below flushes whenever grid.y differs, so the two groups go out as separate launches.
+            rag.k = 1;
         }
         const int kper = (KIT + KS - 1) / KS;
         const int KS2 = (KIT + kper - 1) / kper;
@@ -2680,9 +2689,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             const int nd = c.taps[0].n, nh = c.taps[1].n, nw = c.taps[2].n, THW = nh * nw;
             const int64_t sc4 = xd.sc * 4;
             a.structured = 0;
-            if (tc.bn == 4) {
-                // thin kernels have their own (per-tap) structured walk, set up above
-            } else if (dstep) {
+            if (walk == 2) {
                 // step = (4 channels, one depth tap, 2x2 inner taps); depth taps walk upwards from the farthest one
                 a.structured = 2;
                 a.s_log2p = nd == 2 ? 1 : nd == 4 ? 2 : 3;
@@ -2694,7 +2701,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                     a.s_local[r] = (int32_t)(4 * (rcl * xd.sc + c.taps[1].delta[uh] * xd.sh + c.taps[2].delta[uw] * xd.sw));
                     a.s_sel[r] = (1u << (8 + uh)) | (1u << (16 + uw));
                 }
-            } else if (16 % T == 0 && RC % (16 / T) == 0 && sc4 * (16 / T) < (1ll << 30)) {
+            } else if (walk == 1) {
                 // every step covers 16/T whole channels with all T taps
                 a.structured = 1;
                 a.s_log2p = 0;
@@ -2705,8 +2712,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                     a.s_local[r] = (int32_t)(4 * (rcl * xd.sc + c.taps[0].delta[ud] * xd.sd + c.taps[1].delta[uh] * xd.sh + c.taps[2].delta[uw] * xd.sw));
                     a.s_sel[r] = (1u << ud) | (1u << (8 + uh)) | (1u << (16 + uw));
                 }
-            } else if (THW == 16 && (nd == 2 || nd == 4 || nd == 8) && c.taps[0].mul == 1 && c.taps[0].base == 0 &&
-                       c.taps[0].delta[nd - 1] == nd - 1 && c.o_ext[0] + nd - 1 <= c.taps[0].size && sc4 < (1ll << 30)) {
+            } else if (walk == 3) {
                 // 4x4 inner taps, step = (channel, depth tap); depth taps never leave the tensor (no depth padding)
                 a.structured = 1;
                 a.s_log2p = nd == 2 ? 1 : nd == 4 ? 2 : 3;
@@ -2769,7 +2775,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         const dim3 grid((unsigned)blocks, (unsigned)KS2);
         const bool dma = a.structured && tc.bn != 4 && !toggles().no_lds_dma;
         if (!dma || KS2 > 1) stat_ok = false;   // only the LDS-DMA kernel's direct epilogue produces the sums
-        if ((rag_m0 > 0 || will_dma) && !dma) return fail(DCV_EINVAL, "%s: internal: the LDS-DMA kernel was planned for a class that does not take it", tag);
+        if (will_dma != dma) return fail(DCV_EINVAL, "%s: internal: structured_walk and the launch setup disagree", tag);
         if (!dma && npack > 0) {   // an immediate launch needs its packed weights now
             int rcp = flush_packs(w, packs, npack, packmax, OC, OCp, ws_o, stream);
             if (rcp != DCV_OK) return rcp;
@@ -3331,12 +3337,20 @@ int dcv_debug_read_stamps(unsigned long long* host, int nblocks) {
 const char* dcv_last_error(void) { return g_err; }
 const char* dcv_debug_last_kernel(void) { return g_last_kernel; }
 int dcv_set_precision(int mode) {
-    if (mode != 0 && mode != 1) return fail(DCV_EINVAL, "set_precision: 0 = fp32, 1 = bf16 MFMA products");
+    if (mode < 0 || mode > 2) return fail(DCV_EINVAL, "set_precision: 0 = fp32, 1 = bf16 MFMA products, 2 = fp32 emulated on the bf16 matrix pipe (3 x bf16 split, 6 products)");
     g_precision.store(mode);
     return DCV_OK;
 }
 int dcv_get_precision(void) { return g_precision.load(); }
-int dcv_version(void) { return 1; }
+int dcv_version(void) { return 2; }
+void dcv_abi_struct_sizes(size_t out[3]) {
+    if (!out) return;
+    out[0] = sizeof(dcv_dims5); out[1] = sizeof(dcv_conv_geom); out[2] = sizeof(dcv_wpack);
+}
+int dcv_conv_effective_precision(const dcv_conv_geom* g) {
+    if (g && g->mfma >= 1 && g->mfma <= 3) return g->mfma;
+    return g_precision.load() + 1;
+}
 uint64_t dcv_launch_count(void) { return g_launches.load(); }
 
 // A transposed convolution of a 1x1(x1) input with stride 1 and no padding (the latent layer, generator.py:61:
@@ -3404,8 +3418,12 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
                          float* stat = nullptr, size_t stat_bytes = 0, int* stat_parts = nullptr, size_t* stat_need = nullptr,
                          const dcv_wpack* pack = nullptr, size_t* pack_need = nullptr, const float* gate = nullptr, float gate_slope = 0.f) {
     // xd = module input dims, yd = module output dims, always.
-    if (g && (g->mfma < 0 || g->mfma > 2)) return fail(DCV_EINVAL, "conv: dcv_conv_geom.mfma must be 0 (process default), 1 (fp32) or 2 (bf16 products)");
+    if (g && (g->mfma < 0 || g->mfma > 3)) return fail(DCV_EINVAL, "conv: dcv_conv_geom.mfma must be 0 (process default), 1 (fp32), 2 (bf16 products) or 3 (fp32 on the bf16 pipe)");
     PrecisionScope prec_scope(g);
+    // a caller-owned packed copy is valid for ONE effective precision (its format depends on it): never read or fill one stamped for another
+    if (pack && pack->buf && !need_only && !pack_need && !stat_need && pack->precision != eff_precision() + 1)
+        return fail(DCV_EINVAL, "conv: dcv_wpack.precision is %d but this call runs at precision %d (1 fp32, 2 bf16 products, 3 fp32-on-bf16): %s",
+                    pack->precision, eff_precision() + 1, pack->ready ? "a ready pack of another format would be read" : "stamp the buffer with dcv_conv_effective_precision(g)");
     {
         dcv_conv_geom g2;
         dcv_dims5 y2;
@@ -3541,7 +3559,7 @@ int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const 
 
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd,
                              float* dw, void* ws, size_t ws_bytes, void* stream) {
-    if (g && (g->mfma < 0 || g->mfma > 2)) return fail(DCV_EINVAL, "conv_bwd_weight: dcv_conv_geom.mfma must be 0, 1 or 2");
+    if (g && (g->mfma < 0 || g->mfma > 3)) return fail(DCV_EINVAL, "conv_bwd_weight: dcv_conv_geom.mfma must be 0, 1, 2 or 3");
     PrecisionScope prec_scope(g);
     {
         dcv_conv_geom g2;

@@ -32,7 +32,8 @@ class Dims5(C.Structure):
 
 class WPack(C.Structure):
     """dcv_wpack: caller-owned K-major packed weights of one (layer, pass, input geometry)."""
-    _fields_ = [("buf", C.c_void_p), ("bytes", C.c_size_t), ("ready", C.c_int32)]
+    _fields_ = [("buf", C.c_void_p), ("bytes", C.c_size_t), ("ready", C.c_int32),
+                ("precision", C.c_int32)]   # dcv_conv_effective_precision(g) the buffer was / is to be packed for: 1 fp32, 2 bf16 products, 3 fp32-on-bf16
 
 
 class ConvGeom(C.Structure):
@@ -40,7 +41,7 @@ class ConvGeom(C.Structure):
                 ("sd", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
                 ("pd", C.c_int32), ("ph", C.c_int32), ("pw", C.c_int32),
                 ("transposed", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
-                ("mfma", C.c_int32)]     # 0 = process default, 1 = fp32, 2 = bf16 products (per-module switch)
+                ("mfma", C.c_int32)]     # 0 = process default, 1 = fp32, 2 = bf16 products, 3 = fp32 emulated on the bf16 pipe (per-module switch)
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)
@@ -52,6 +53,8 @@ _G = C.POINTER(ConvGeom)
 _SIGS = {
     "dcv_last_error": (C.c_char_p, []),
     "dcv_version": (C.c_int, []),
+    "dcv_abi_struct_sizes": (None, [C.POINTER(C.c_size_t)]),
+    "dcv_conv_effective_precision": (C.c_int, [_G]),
     "dcv_launch_count": (C.c_uint64, []),
     "dcv_debug_kernel_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "dcv_debug_last_kernel": (C.c_char_p, []),
@@ -93,6 +96,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
+ABI_VERSION = 2
 _lib = None
 _lock = threading.Lock()
 
@@ -112,6 +116,14 @@ def lib():
                     fn = getattr(l, name)  # AttributeError here = header/library mismatch
                     fn.restype = res
                     fn.argtypes = args
+                # the library cannot see how large the structs behind our pointers are: compare declarations before the first real call
+                if l.dcv_version() != ABI_VERSION:
+                    raise NativeError(f"{LIB_PATH} speaks ABI version {l.dcv_version()}, this binding was written for {ABI_VERSION}: rebuild the library")
+                sizes = (C.c_size_t * 3)()
+                l.dcv_abi_struct_sizes(sizes)
+                mine = (C.sizeof(Dims5), C.sizeof(ConvGeom), C.sizeof(WPack))
+                if tuple(sizes) != mine:
+                    raise NativeError(f"struct sizes differ: library {tuple(sizes)} vs binding {mine} (dcv_dims5, dcv_conv_geom, dcv_wpack)")
                 _lib = l
     return _lib
 
@@ -121,13 +133,27 @@ def check(rc: int, what: str):
         raise NativeError(f"{what} failed (code {rc}): {lib().dcv_last_error().decode(errors='replace')}")
 
 
-PRECISION_CODE = {None: 0, "default": 0, "fp32": 1, "bf16": 2}
+PRECISION_CODE = {None: 0, "default": 0, "fp32": 1, "bf16": 2, "f32x6": 3}
 
 
 def set_precision(mode: str):
-    """PROCESS DEFAULT — 'fp32' or 'bf16': bf16 MFMA products with fp32 accumulation in the large GEMM kernels (throughput mode).
-    Modules can override it one by one: dcvgan_amd.util.set_precision(module, "bf16" | "fp32" | None)."""
-    check(lib().dcv_set_precision({"fp32": 0, "bf16": 1}[mode]), "dcv_set_precision")
+    """PROCESS DEFAULT — 'fp32', 'bf16' (bf16 MFMA products with fp32 accumulation in the large GEMM kernels: throughput mode) or 'f32x6'
+    (experimental: fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulation — fp32-grade results on the
+    16x faster matrix pipe).  Modules can override it one by one: dcvgan_amd.util.set_precision(module, "bf16" | "fp32" | "f32x6" | None)."""
+    check(lib().dcv_set_precision({"fp32": 0, "bf16": 1, "f32x6": 2}[mode]), "dcv_set_precision")
+
+
+def csrc_digest() -> str:
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.h, build.sh, the public header).  Profiles committed under
+    profiles/ carry it, so a number measured on other kernels is never attached to this build (bench.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h", ".sh")))
+    for f in [os.path.join(src, f) for f in files] + [os.path.join(os.path.dirname(_HERE), "include", "dcvgan_hip.h")]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def launch_count() -> int:

@@ -112,7 +112,8 @@ class _PackCache:
     def get(self, w, which, g, xd_t, yd_t, xd, yd):
         key = (which, g.key(), tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
         e = self.entries.get(key)
-        stamp = (w._version, w.data_ptr(), g.mfma or 1 + lib().dcv_get_precision())     # the bf16-product kernels read a bf16-packed copy
+        prec = lib().dcv_conv_effective_precision(C.byref(g))                              # the packed FORMAT depends on it; the library checks the stamp too
+        stamp = (w._version, w.data_ptr(), prec)
         if _POISON:
             # debug builds of the tests: edits autograd cannot see (`p.data.normal_()`, raw-pointer writes) do not bump the version;
             # a checksum of the live weights in the stamp turns "silently convolving with stale packed weights" into a repack
@@ -125,7 +126,7 @@ class _PackCache:
             e = self.entries[key] = [None, torch.empty(nbytes, dtype=torch.uint8, device=w.device)]
         ready = e[0] == stamp
         e[0] = None                     # not valid again until the launch that (re)packs it has been accepted: see commit()
-        pk = N.WPack(e[1].data_ptr(), e[1].numel(), int(ready))
+        pk = N.WPack(e[1].data_ptr(), e[1].numel(), int(ready), prec)
         pk._entry, pk._stamp = e, stamp
         return pk
 
@@ -163,6 +164,10 @@ def invalidate_packed_weights(obj) -> None:
 
 
 class _Conv(Function):
+    # identity token of the current backward pass: a weight's gradient slot is handed out once per backward (new_backward_epoch() is called by
+    # the optimiser wrapper's step(), i.e. between two backwards of the same bucket)
+    _epoch = [object()]
+
     @staticmethod
     def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None, act_slot=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
@@ -245,11 +250,24 @@ class _Conv(Function):
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:
-            dw = _empty(w.shape, w.device)
+            # data parallel: the parameter's slice of its bucket's flat gradient buffer (optim.GradBucket) — the first weight gradient of a
+            # backward is written straight into it (autograd adopts the returned tensor as .grad); a second use of the same weight in one
+            # backward (D on the real and the fake batch) gets a tensor of its own, which autograd adds
+            slot = getattr(w, "_dcv_grad_slot", None)
+            if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _Conv._epoch[0]:
+                w._dcv_slot_epoch = _Conv._epoch[0]
+                dw = slot.detach()
+            else:
+                dw = _empty(w.shape, w.device)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
         return dx, dw, None, None, None, None, None, None, None
+
+
+def new_backward_epoch():
+    """Called when the gradients of the last backward have been consumed (optimiser step): weight-gradient slots may be handed out again."""
+    _Conv._epoch[0] = object()
 
 
 def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None, act_slot=None):

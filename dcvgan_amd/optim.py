@@ -84,11 +84,13 @@ class Adam:
 class GradBucket:
     """The gradients that one backward produces and one group of optimiser steps consumes.
 
-    `dirty` is set by autograd (post-accumulate-grad hooks) whenever a member parameter receives a
-    gradient and cleared by `reduce()`.  `reduce()` flattens every present gradient into one buffer,
-    all-reduces it (sum) and re-points each `p.grad` at its slice of the reduced buffer (no copy back).
-    Parameters whose `.grad` is None are skipped; the set is the same on every rank because every rank
-    runs the same graph."""
+    Round 4: the bucket owns ONE persistent flat fp32 buffer (allocated at the first reduction, sized for all members) and every
+    member's ``.grad`` IS its slice of it: the post-accumulate-grad hook — which also marks the bucket dirty — re-points ``p.grad`` at
+    the slice (copying only when the gradient was produced elsewhere: a parameter used twice in one backward is summed by autograd into
+    a tensor of its own; the weight-gradient kernels of single-use parameters write straight into the slice, ``ops._Conv.backward``).
+    ``reduce()`` is then one in-place all-reduce (sum) of the buffer — no flatten copy, no re-pointing afterwards.  Parameters whose
+    ``.grad`` is None this backward keep a stale slice that nobody reads (the set is the same on every rank: every rank runs the same graph).
+    `dirty` is set by autograd whenever a member receives a gradient and cleared by `reduce()`."""
 
     def __init__(self, group=None, bucket_bytes: int = 256 << 20):
         import torch.distributed as dist
@@ -99,12 +101,46 @@ class GradBucket:
         self.dirty = False
         self.collectives = 0      # counters for tests / bench
         self.reductions = 0
+        self.copies = 0           # gradients that had to be copied into their slice (produced outside it)
         self._hooks = []
+        self._flat: Optional[torch.Tensor] = None
+        self._chunks = []         # [(start, end)] element ranges of the buffer, one collective each (bucket_bytes caps a message)
 
-    def _mark(self, _param):
+    def _layout(self):
+        """Allocate the flat buffer and hand every member its slice (`p._dcv_grad_slot`, read by the weight-gradient ops)."""
+        p0 = self.params[0]
+        total, self._chunks, start = 0, [], 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise NativeError("GradBucket: fp32 parameters only")
+            n = p.numel()
+            if total > start and (total - start + n) * 4 > self.bucket_bytes:
+                self._chunks.append((start, total))
+                start = total
+            p._dcv_grad_off = total
+            total += (n + 63) // 64 * 64          # slices start on 256-byte boundaries (16-byte stores of the reduce kernels)
+        self._chunks.append((start, total))
+        self._flat = torch.zeros(total, dtype=torch.float32, device=p0.device)
+        for p in self.params:
+            p._dcv_grad_slot = self._flat[p._dcv_grad_off:p._dcv_grad_off + p.numel()].view(p.shape)
+
+    def _mark(self, p):
         self.dirty = True
+        if self.world == 1 and not self._force_layout:
+            return
+        if self._flat is None or self._flat.device != p.device:
+            self._layout()
+        g, slot = p.grad, p._dcv_grad_slot
+        if g is not None and g.data_ptr() != slot.data_ptr():
+            slot.copy_(g)
+            p.grad = slot
+            self.copies += 1
+
+    _force_layout = False
 
     def add(self, params: Iterable[torch.nn.Parameter]):
+        if self._flat is not None:
+            raise NativeError("GradBucket.add after the flat buffer was laid out")
         for p in params:
             self.params.append(p)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._mark))
@@ -118,24 +154,17 @@ class GradBucket:
         self.dirty = False
         if self.world == 1 and not (force and self.dist.is_initialized()):
             return
+        if self._flat is None:      # gradients arrived before the layout existed (world of one, force=True): adopt them now
+            self._layout()
+        for p in self.params:
+            if p.grad is not None and p.grad.data_ptr() != p._dcv_grad_slot.data_ptr():
+                p._dcv_grad_slot.copy_(p.grad)
+                p.grad = p._dcv_grad_slot
+                self.copies += 1
         self.reductions += 1
-        owners = [p for p in self.params if p.grad is not None]
-        chunk, size = [], 0
-        for p in owners + [None]:
-            if p is None or (chunk and size + p.grad.numel() * 4 > self.bucket_bytes):
-                if chunk:
-                    flat = torch.cat([b.grad.reshape(-1) for b in chunk])
-                    self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-                    self.collectives += 1
-                    off = 0
-                    for b in chunk:
-                        n = b.grad.numel()
-                        b.grad = flat[off:off + n].view(b.grad.shape)
-                        off += n
-                chunk, size = [], 0
-            if p is not None:
-                chunk.append(p)
-                size += p.grad.numel() * 4
+        for a, b in self._chunks:
+            self.dist.all_reduce(self._flat[a:b], op=self.dist.ReduceOp.SUM, group=self.group)
+            self.collectives += 1
 
 
 class DataParallelAdam:
@@ -162,6 +191,8 @@ class DataParallelAdam:
         self.bucket.reduce()
         self.inner.grad_scale = 1.0 / self.world
         self.inner.step()
+        from . import ops
+        ops.new_backward_epoch()      # this backward's gradients are consumed: the weight-gradient ops may write into the slices again
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):

@@ -56,13 +56,19 @@ typedef struct dcv_conv_geom {
     int32_t pd, ph, pw;
     int32_t transposed;
     int32_t cin, cout;
-    /* precision of the MFMA products for THIS module's three passes: 0 = the process default (dcv_set_precision), 1 = fp32, 2 = bf16 products
-     * (round 3: a per-module switch; dcvgan_amd.util.set_precision(module, "bf16") sets it on a module's convolutions) */
+    /* precision of the MFMA products for THIS module's three passes: 0 = the process default (dcv_set_precision), 1 = fp32, 2 = bf16 products,
+     * 3 = fp32 emulated on the bf16 matrix pipe (each operand split into three bf16 pieces, 6 products, fp32 accumulation — see dcv_set_precision)
+     * (a per-module switch; dcvgan_amd.util.set_precision(module, "bf16") sets it on a module's convolutions) */
     int32_t mfma;
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
+/* ABI version.  2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
+ * A host compares dcv_version() and dcv_abi_struct_sizes() with its own declarations BEFORE the first call that passes a struct
+ * (dcvgan_amd/native.py does, and refuses to load on a mismatch): the library cannot see the size of what a pointer points to. */
 int dcv_version(void);
+/* out[0..2] = sizeof(dcv_dims5), sizeof(dcv_conv_geom), sizeof(dcv_wpack) as this library was compiled */
+void dcv_abi_struct_sizes(size_t out[3]);
 /* number of kernel launches issued through this library so far (tests use it to
  * prove the HIP path, not a fallback, did the work) */
 uint64_t dcv_launch_count(void);
@@ -70,8 +76,15 @@ uint64_t dcv_launch_count(void);
  * and the headline benchmark refer to), 1 = bf16 products with fp32 accumulation (v_mfma_f32_32x32x16_bf16): tensors,
  * weights, BatchNorm statistics and optimiser state stay fp32, only the MFMA fragments are rounded (RNE) as they are read
  * from LDS.  A throughput mode for BASELINE.json's bf16 / fp16 configs; the reference itself is fp32-only. */
+/* mode 2 (round 4, experimental, never the default): fp32 EMULATED on the bf16 matrix pipe.  Every fp32 operand is split exactly into three bf16 pieces
+ * x = hi + mid + lo (RNE at each level); a bf16 x bf16 product is exact in fp32, and the six products of total order <= 2 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi,
+ * mid*mid) are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 — the dropped terms are <= 2^-23 of a product, the size of fp32's own rounding of it.  6 bf16
+ * MFMAs (192 cycles) replace 8 fp32 ones (512 cycles) per 32 x 32 x 16 block; error against fp64 measured beside the native kernel's in profiles/r04_f32x6_*. */
 int dcv_set_precision(int mode);
 int dcv_get_precision(void);
+/* the precision code (1 fp32, 2 bf16 products, 3 fp32-on-bf16) a dcv_conv_* call with this geometry would run at right now: g->mfma, or the process default
+ * when that is 0.  A caller that owns packed weights (dcv_wpack) stamps them with it. */
+int dcv_conv_effective_precision(const dcv_conv_geom* g);
 /* diagnostics: which GEMM kernel instance the calling thread's last dcv_conv_* call launched (bench.py / tools label
  * their per-layer timings with it) */
 const char* dcv_debug_last_kernel(void);
@@ -92,11 +105,17 @@ size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, cons
  * Weights only change at optimiser steps (trainer.py:320-322,357-359) while each layer runs 2-3 times per phase, so a
  * caller may own the packed copy instead: a buffer of dcv_conv_packed_bytes(g, x, y, which) bytes per (layer, which,
  * input geometry), passed with ready = 0 the first time after the weights changed (the call packs into it) and
- * ready = 1 afterwards (the packing launches are skipped).  pack = NULL keeps the default. */
+ * ready = 1 afterwards (the packing launches are skipped).  pack = NULL keeps the default.
+ * A packed copy is valid for ONE (weights, effective precision) pair — the packed FORMAT depends on the precision (fp32 [k][OCp]; bf16 products
+ * [k/8][OCp][8] bf16; fp32-on-bf16: three such planes).  `precision` carries that pair's second half across the ABI: the caller sets it to
+ * dcv_conv_effective_precision(g) when it hands the buffer over with ready = 0, keeps it with the buffer, and passes it back with ready = 1; a call whose
+ * own effective precision differs from a ready pack's returns DCV_EINVAL before any launch (it never reads a pack of the other format), and a
+ * ready = 0 call whose `precision` is not the call's own is refused the same way.  precision = 0 is refused too: there is no "unchecked" pack. */
 typedef struct dcv_wpack {
     float* buf;
     size_t bytes;
     int32_t ready;
+    int32_t precision;   /* 1 fp32, 2 bf16 products, 3 fp32-on-bf16: what `buf` was / is to be packed for */
 } dcv_wpack;
 size_t dcv_conv_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which /*0 fwd,1 bwd-data*/);
 int dcv_conv_forward(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w,

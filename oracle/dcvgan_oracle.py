@@ -108,6 +108,7 @@ class KinkTape:
         """`masks=None`: RECORD this evaluation's own patterns into `self.recorded` instead of replaying."""
         self.masks, self.pos, self.mismatch = masks, 0, []
         self.recorded = [] if masks is None else None
+        self.last_bn = None      # (state-dict prefix, per-channel |mean| / std of that BatchNorm's input): names the furthest mismatch
 
     def __enter__(self):
         KinkTape.active = self
@@ -128,7 +129,17 @@ class KinkTape:
         bad = own != m
         n = int(bad.sum())
         far = float(x.detach()[bad].abs().max() / x.detach().pow(2).mean().sqrt()) if n else 0.0
-        self.mismatch.append((n, x.numel(), far, tuple(x.shape)))
+        where = None
+        if n:   # which layer / channel the furthest mismatch sits in, and how ill-conditioned that BatchNorm channel is
+            xa = torch.where(bad, x.detach().abs(), torch.zeros((), dtype=x.dtype))
+            ch = int(xa.flatten(2).amax(dim=(0, 2)).argmax()) if x.dim() >= 3 else -1
+            bn = self.last_bn
+            if bn is not None and ch >= 0 and bn[1].numel() == x.shape[1]:
+                where = (bn[0], ch, float(bn[1][ch]))
+            else:
+                where = ("(no BatchNorm in front)", ch, 0.0)
+        self.last_bn = None
+        self.mismatch.append((n, x.numel(), far, tuple(x.shape), where))
         return m
 
 
@@ -155,6 +166,10 @@ def _lrelu(x: torch.Tensor, slope: float) -> torch.Tensor:
 def _bn(st: State, prefix: str, x: torch.Tensor, training: bool) -> torch.Tensor:
     """nn.BatchNorm{2,3}d forward incl. running-stat side effects."""
     rm, rv = st[prefix + ".running_mean"], st[prefix + ".running_var"]
+    if KinkTape.active is not None and KinkTape.active.masks is not None:
+        with torch.no_grad():
+            xf = x.detach().transpose(0, 1).flatten(1).double()
+            KinkTape.active.last_bn = (prefix, xf.mean(1).abs() / xf.std(1).clamp_min(1e-300))
     if training:
         st[prefix + ".num_batches_tracked"] += 1
     return F.batch_norm(x, rm, rv, st[prefix + ".weight"], st[prefix + ".bias"],

@@ -34,8 +34,33 @@ def test_header_symbols_are_exported(lib):
     assert set(names) == set(native.EXPORTS), (set(names) ^ set(native.EXPORTS))
 
 
+def test_integration_md_declares_the_structs_the_library_has(lib):
+    """INTEGRATION.md's binding snippet is what a maintainer copies: its struct declarations must be the ones the library was compiled
+    with (round 3 shipped a 12-field dcv_conv_geom there after the 13th field was added)."""
+    from dcvgan_amd import native
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class ConvGeom\(C\.Structure\):.*?_fields_ = \[\(n, C\.c_int32\) for n in \(([^)]*)\)\]", text, flags=re.S)
+    assert m, "INTEGRATION.md no longer shows the ConvGeom binding"
+    doc_fields = [f.strip().strip('"') for f in m.group(1).split(",")]
+    assert doc_fields == [f for f, _ in native.ConvGeom._fields_]
+    m = re.search(r"class WPack\(C\.Structure\):.*?_fields_ = \[(.*?)\]\n", text, flags=re.S)
+    assert m and re.findall(r'\("(\w+)"', m.group(1)) == [f for f, _ in native.WPack._fields_]
+    # ... and the header's own field lists
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "dcvgan_hip.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct dcv_conv_geom \{(.*?)\} dcv_conv_geom;", hdr, flags=re.S).group(1)
+    names = [n.strip() for decl in re.findall(r"int32_t ([^;]*);", body) for n in decl.split(",")]
+    assert names == [f for f, _ in native.ConvGeom._fields_]
+    body = re.search(r"typedef struct dcv_wpack \{(.*?)\} dcv_wpack;", hdr, flags=re.S).group(1)
+    assert re.findall(r"(\w+);", body) == [f for f, _ in native.WPack._fields_]
+    sizes = (ctypes.c_size_t * 3)()
+    lib.dcv_abi_struct_sizes(sizes)
+    assert tuple(sizes) == (ctypes.sizeof(native.Dims5), ctypes.sizeof(native.ConvGeom), ctypes.sizeof(native.WPack))
+    assert lib.dcv_version() == native.ABI_VERSION == 2
+    assert re.search(r"lib\.dcv_version\(\) == 2", text)
+
+
 def test_version_and_error_channel(lib):
-    assert lib.dcv_version() >= 1
+    assert lib.dcv_version() >= 2
     assert isinstance(lib.dcv_last_error(), bytes)
     assert lib.dcv_launch_count() == 0  # nothing launched on a CPU-only box
 
@@ -58,10 +83,20 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.dcv_conv_packed_bytes(ctypes.byref(g), ctypes.byref(x), ctypes.byref(y_ok), 2) == 0
     # the per-module precision field: 0 (process default), 1 (fp32), 2 (bf16 products); anything else is refused on the host
     assert ctypes.sizeof(ConvGeom) == 13 * 4 and [f for f, _ in ConvGeom._fields_][-1] == "mfma"
-    g_bad = ConvGeom(1, 4, 4, 1, 2, 2, 0, 1, 1, 0, 3, 8, 3)
+    g_bad = ConvGeom(1, 4, 4, 1, 2, 2, 0, 1, 1, 0, 3, 8, 4)
     assert lib.dcv_conv_workspace_bytes(ctypes.byref(g_bad), ctypes.byref(x), ctypes.byref(y_ok), 0) == 0 and b"mfma" in lib.dcv_last_error()
     g_bf = ConvGeom(1, 4, 4, 1, 2, 2, 0, 1, 1, 0, 3, 8, 2)
     assert lib.dcv_conv_workspace_bytes(ctypes.byref(g_bf), ctypes.byref(x), ctypes.byref(y_ok), 0) > 0
+    # a caller-owned packed copy is stamped with the precision it was packed for; a call at another precision refuses it on the host
+    from dcvgan_amd.native import WPack
+    assert lib.dcv_conv_effective_precision(ctypes.byref(g)) == 1 and lib.dcv_conv_effective_precision(ctypes.byref(g_bf)) == 2
+    fake = ctypes.create_string_buffer(64)      # never dereferenced: the stamp check comes before any launch
+    pk = WPack(ctypes.addressof(fake), 1 << 20, 1, 2)
+    assert lib.dcv_conv_forward(ctypes.byref(g), ctypes.addressof(fake), ctypes.byref(x), ctypes.addressof(fake), ctypes.addressof(fake), ctypes.byref(y_ok), 0, 0.0,
+                                ctypes.byref(pk), None, 0, None) == -1 and b"dcv_wpack.precision" in lib.dcv_last_error()
+    pk0 = WPack(ctypes.addressof(fake), 1 << 20, 0, 0)
+    assert lib.dcv_conv_forward(ctypes.byref(g), ctypes.addressof(fake), ctypes.byref(x), ctypes.addressof(fake), ctypes.addressof(fake), ctypes.byref(y_ok), 0, 0.0,
+                                ctypes.byref(pk0), None, 0, None) == -1 and b"dcv_wpack.precision" in lib.dcv_last_error()
 
 
 def test_product_path_has_no_cpu_fallback(lib):

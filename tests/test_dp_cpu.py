@@ -97,6 +97,78 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_gated(rank, world, port, q):
+    """The trainer's gating at world 4 (surreal-depth1: num_gen_update = 2): per iteration a D-phase backward that is only taken — and whose
+    three optimisers are only stepped — on even iterations, then a G-phase backward + the ggen / cgen / ggen steps every iteration.  Two buckets
+    (D: three members, G: two), one collective per taken backward, none for a gated-off phase; every .grad IS its slice of the bucket's flat
+    buffer afterwards; replicas stay bit-identical."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dcvgan_amd import optim
+    torch.manual_seed(7 + rank)
+    dis = [torch.nn.Linear(4, 3), torch.nn.Linear(4, 2), torch.nn.Linear(4, 1)]
+    gen = [torch.nn.Linear(5, 4), torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Tanh())]
+    for n in dis + gen:
+        optim.broadcast_module(n)
+    bD, bG = optim.GradBucket(), optim.GradBucket()
+    oD = [optim.DataParallelAdam(_SGD(n.parameters(), 0.05), bD) for n in dis]
+    oG = [optim.DataParallelAdam(_SGD(n.parameters(), 0.05), bG) for n in gen]
+    ok = True
+    gd = torch.Generator().manual_seed(100 + rank)       # per-rank data
+    want_D = want_G = 0
+    for it in range(1, 5):
+        z = torch.randn(6, 5, generator=gd)
+        real = torch.randn(6, 4, generator=gd)
+        for n in dis:
+            n.zero_grad()
+        fake = gen[1](gen[0](z))                          # NOT detached: the D-phase backward also runs through the generators (trainer.py:304-319)
+        loss_d = sum((d(real) ** 2).mean() + (d(fake) ** 2).mean() for d in dis)
+        if it % 2 == 0:
+            loss_d.backward()
+            before = bD.collectives
+            for o in oD:
+                o.step()
+            want_D += 1
+            ok &= bD.collectives == before + 1            # ONE collective for the three members
+            ok &= all(p.grad is not None and p.grad.data_ptr() == p._dcv_grad_slot.data_ptr() for n in dis for p in n.parameters())
+        else:
+            before = bD.collectives
+            for o in oD:
+                o.step()                                  # a trainer that stepped anyway must not start a collective: nothing is dirty
+            ok &= bD.collectives == before or it > 1      # (iteration 1: nothing ever arrived; later: the G phase's dead D gradients did arrive)
+        for n in gen:
+            n.zero_grad()
+        fake = gen[1](gen[0](z))
+        loss_g = sum(-(d(fake)).mean() for d in dis[:2])  # hinge: the third discriminator takes no part in the G loss (loss.py:190-191)
+        loss_g.backward()
+        before = bG.collectives
+        oG[0].step(); oG[1].step(); oG[0].step()          # ggen, cgen, ggen (trainer.py:357-359)
+        want_G += 1
+        ok &= bG.collectives == before + 1 and bG.reductions == want_G
+        ok &= all(p.grad.data_ptr() == p._dcv_grad_slot.data_ptr() for n in gen for p in n.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for n in dis + gen for p in n.parameters()])
+    allw = [None] * world
+    dist.all_gather_object(allw, flat.numpy())
+    ok &= all((a == allw[0]).all() for a in allw)
+    ok &= bD._flat is not None and bD._flat.numel() >= sum(p.numel() for n in dis for p in n.parameters())
+    q.put((rank, bool(ok), bD.reductions, bG.reductions))
+    dist.destroy_process_group()
+
+
+def test_dp_gating_world4_gloo():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gated, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(r[:2] for r in res) == [(r, True) for r in range(4)], res
+    assert all(r[3] == 4 for r in res), res              # four G-phase reductions
+
+
 def test_dp_wrapper_world2_gloo():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")

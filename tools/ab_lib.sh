@@ -6,6 +6,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 X=$1; P=${2:-3}; shift; shift
 SO=dcvgan_amd/libdcvgan_hip.so
 cp $SO /tmp/base.so
+trap 'cp /tmp/base.so $SO' EXIT      # whatever ends the script (a failed bench, a timeout, an interrupt), the shipped build is back in place
 O=/tmp/ab_obj; mkdir -p $O
 F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Iinclude -Idcvgan_amd/csrc -mllvm -amdgpu-mfma-vgpr-form $X"
 hipcc $F -c dcvgan_amd/csrc/conv_mfma.hip -o $O/conv_mfma.o 2> $O/conv.log &

@@ -22,7 +22,12 @@ for tag in ("FETCH", "WRITE", "SQ"):
             seen.add((r["Dispatch_Id"], tag))
             out[k]["dur_ns_" + tag] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
             out[k]["dispatches"] = max(out[k]["dispatches"], 0) + (1 if tag == "SQ" else 0)
+import os, sys
+sys.path.insert(0, os.getcwd())
+from dcvgan_amd import native
+out["__meta__"] = {"config": "isogd-depth", "batch": 70, "steps": 2, "csrc_sha256": native.csrc_digest(), "git_head": os.environ.get("GIT_HEAD")}
 json.dump(out, open("gpurun_out/pmc_step/summary.json", "w"), indent=1)
+del out["__meta__"]
 kb = sum(v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0) for v in out.values())
 print("HBM GB per step (FETCH+WRITE, raw):", kb * 1024 / 2 / 1e9)
 gui = max(v.get("GRBM_GUI_ACTIVE", 0) for v in out.values())
