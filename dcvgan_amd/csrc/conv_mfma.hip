@@ -71,6 +71,38 @@ __device__ __forceinline__ bf16x8 pack_bf16x8(const float (&t)[8]) {
     return __builtin_bit_cast(bf16x8, w);
 }
 
+// fp32 on the bf16 matrix pipe (precision mode 2, "f32x6"): x = hi + mid + lo EXACTLY, each piece the bf16 RNE of what the pieces before it left
+// (|mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|; 8 + 8 + 8 significand bits cover fp32's 24).  A bf16 x bf16 product is exact in fp32, so
+// sum_k a_k b_k = sum_k sum_{p,q} a_k^(p) b_k^(q); the six terms with p + q <= 2 are formed by v_mfma_f32_32x32x16_bf16 and accumulated in fp32,
+// the three dropped ones (mid*lo, lo*mid, lo*lo) are <= 2^-26 of a product each — below fp32's own rounding of it (2^-24).
+// 11 VALU operations per pair of elements: v_cvt_pk_bf16_f32, two re-widenings (shift / mask), two subtractions — twice — and the last conversion.
+__device__ __forceinline__ void split3_bf16x8(const float (&t)[8], bf16x8 (&o)[3]) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    u32x4_ h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2_ f = {t[2 * q], t[2 * q + 1]};
+        const uint32_t hw = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_));
+        const f32x2_ r = {f[0] - __builtin_bit_cast(float, hw << 16), f[1] - __builtin_bit_cast(float, hw & 0xffff0000u)};
+        const uint32_t mw = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2_));
+        const f32x2_ r2 = {r[0] - __builtin_bit_cast(float, mw << 16), r[1] - __builtin_bit_cast(float, mw & 0xffff0000u)};
+        h[q] = hw; m[q] = mw; l[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2_));
+    }
+    o[0] = __builtin_bit_cast(bf16x8, h); o[1] = __builtin_bit_cast(bf16x8, m); o[2] = __builtin_bit_cast(bf16x8, l);
+}
+// the six products, smallest terms first (a = the A operand's pieces, b = the B operand's)
+#define DCV_MFMA_X6(ACC, A3, B3)                                                              \
+    {                                                                                         \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A3)[2], (B3)[0], ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A3)[0], (B3)[2], ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A3)[1], (B3)[1], ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A3)[1], (B3)[0], ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A3)[0], (B3)[1], ACC, 0, 0, 0);        \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16((A3)[0], (B3)[0], ACC, 0, 0, 0);        \
+    }
+
 #ifdef DCV_STAMP
 // diagnostic build only: per-wave cycle totals of the K-loop segments (never in the shipped library)
 __device__ unsigned long long g_stamp[4096][4][6];
@@ -535,8 +567,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 // data gradients, where 20-30 % of the (position, depth tap) pairs are padding.  Steps whose depth tap is
 // outside the tensor for every position of the tile are skipped outright; for the rest the tap's validity
 // is OR-ed into the per-lane voffsets (one VALU op per DMA).
-template <int TOC, int TM, int WOC, int WM, bool DSTEP, bool PATCH, bool BF = false>
-__global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
+// BF: 0 = fp32 MFMA, 1 = bf16 products, 2 = fp32 on the bf16 pipe (three bf16 pieces per operand, six products; split3_bf16x8)
+template <int TOC, int TM, int WOC, int WM, bool DSTEP, bool PATCH, int BF = 0>
+__global__ __launch_bounds__(256, (BF == 2 ? 3 : 4)) void gather_gemm_dma_kernel(const GatherArgsPack pack) {
     constexpr int BN = 32 * TOC * WOC;
     constexpr int BM = 32 * TM * WM;
     // XCD-aware workgroup -> tile mapping.  Workgroup ids go round-robin over the 8 XCDs, each with its own
@@ -554,12 +587,14 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
     unsigned long long q_wait = 0, q_loop = 0;
 #endif
     constexpr int XPT = 16 * BM / 256;
-    // W tile of a K step in 16-byte granules: fp32 [16][BN] floats; bf16 products: packed bf16 [2][BN][8] (PackArgs.fmt 1), half the bytes
-    constexpr int WF4 = BF ? 2 * BN : 16 * BN / 4;
+    // W tile of a K step in 16-byte granules: fp32 [16][BN] floats; bf16 products: packed bf16 [2][BN][8] (PackArgs.fmt 1), half the bytes;
+    // fp32 on the bf16 pipe: three such planes [3][2][BN][8] (PackArgs.fmt 2)
+    constexpr int WF4 = BF == 2 ? 6 * BN : BF ? 2 * BN : 16 * BN / 4;
     constexpr int WPT = (WF4 + 255) / 256;
+    constexpr int WSZ = BF == 2 ? 24 * BN : 16 * BN;   // floats per W buffer
     static_assert(WOC * WM == 4, "4 waves");
-    // ONE LDS array: [2][16][BM] X tiles then [2][16][BN] W tiles
-    __shared__ __attribute__((aligned(16))) float smem[2 * 16 * BM + 2 * 16 * BN];
+    // ONE LDS array: [2][16][BM] X tiles then [2][WSZ] W tiles
+    __shared__ __attribute__((aligned(16))) float smem[2 * 16 * BM + 2 * WSZ];
     float* const Xs = smem;
     float* const Ws = smem + 2 * 16 * BM;
 
@@ -685,7 +720,7 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
             wvo[j] = (uint32_t)(4 * (row * a.OCp + oc0 + c4 * 4));
         }
     }
-    const int wstep4 = BF ? 2 * a.OCp * 16 : 16 * a.OCp * 4;
+    const int wstep4 = BF == 2 ? 6 * a.OCp * 16 : BF ? 2 * a.OCp * 16 : 16 * a.OCp * 4;
 
 #ifdef DCV_STAMP
     __builtin_amdgcn_sched_barrier(0);
@@ -736,14 +771,14 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         const int it_ = (IT);                                                                                           \
         const int soff_ = (it_ >> a.s_log2p) * a.s_stepA + (it_ & ((1 << a.s_log2p) - 1)) * a.s_stepD;                  \
         _Pragma("unroll") for (int i = 0; i < (PATCH ? NS : XPT); ++i) DCV_ISSUE_X(it_, soff_, BUF, i)                  \
-        float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
+        float* wb_ = Ws + (BUF) * WSZ;                                                                                  \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                 \
             if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4) /* wave-uniform: whole waves only */                       \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], it_ * wstep4, 0, 0); \
     }
 #define DCV_ISSUE_W(IT, BUF)                                                                                            \
     {                                                                                                                   \
-        float* wb_ = Ws + (BUF) * 16 * BN;                                                                              \
+        float* wb_ = Ws + (BUF) * WSZ;                                                                                  \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                 \
             if (WF4 % 256 == 0 || wave * 64 + 256 * j < WF4)                                                            \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(wb_ + (wave * 64 + 256 * j) * 4), 16, wvo[j], (IT) * wstep4, 0, 0); \
@@ -790,8 +825,34 @@ __global__ __launch_bounds__(256, 4) void gather_gemm_dma_kernel(const GatherArg
         j = nx;
         DCV_ISSUE_W(itn, buf ^ 1)
         const float* xt = Xs + buf * 16 * BM;
-        const float* wt = Ws + buf * 16 * BN;
-        if constexpr (BF) {
+        const float* wt = Ws + buf * WSZ;
+        if constexpr (BF == 2) {
+            // fp32 on the bf16 pipe: the weights arrive pre-split (three 16-byte LDS reads per A fragment), the activations are split here;
+            // six v_mfma_f32_32x32x16_bf16 per (i, j) cover the step's 16 k rows
+#pragma unroll
+            for (int i = 0; i < (PATCH ? NS : XPT); ++i) DCV_ISSUE_X(itn, soffn, buf ^ 1, i)
+            bf16x8 a8[TOC][3], b8[TM][3];
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    a8[i][pc] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(wt) + 16 * ((pc * 2 + lhi) * BN + (woc * TOC + i) * 32 + l31));
+#pragma unroll
+            for (int jj = 0; jj < TM; ++jj) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    t[q] = PATCH ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xt) + (fbb[PATCH ? jj : 0] + koff8[PATCH ? q : 0]))
+                                 : xt[(8 * lhi + q) * BM + (wm * TM + jj) * 32 + l31];
+                split3_bf16x8(t, b8[jj]);
+            }
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TM; ++jj) DCV_MFMA_X6(acc[i][jj], a8[i], b8[jj])
+            __builtin_amdgcn_s_setprio(0);
+            continue;
+        } else if constexpr (BF == 1) {
             // one v_mfma_f32_32x32x16_bf16 per (i, j) covers the step's 16 k rows: the next tile's X DMAs go out first,
             // then 8 LDS reads + 4 packed conversions per fragment
 #pragma unroll
@@ -1494,7 +1555,8 @@ struct PackArgs {
     const KEntry* ktab[4];
     float* wp[4];
     int32_t K16[4];
-    int32_t fmt[4];   // 0: fp32 wp[k][OCp]; 1: bf16 wp16[k / 8][OCp][8] (the bf16-product LDS-DMA kernels: an MFMA A fragment is one 16-byte LDS read)
+    int32_t fmt[4];   // 0: fp32 wp[k][OCp]; 1: bf16 wp16[k / 8][OCp][8] (the bf16-product LDS-DMA kernels: an MFMA A fragment is one 16-byte LDS read);
+                      // 2: fp32 on the bf16 pipe: wp16[k / 16][piece 0..2][(k / 8) & 1][OCp][8], piece = hi / mid / lo of the 3-way bf16 split
 };
 __global__ void pack_weights_kernel(const float* __restrict__ w, const PackArgs pa, int OC, int OCp, int64_t ws_o) {
     const int c = blockIdx.y;
@@ -1504,7 +1566,15 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const PackArgs 
     const KEntry e = pa.ktab[c][k];
     float v = 0.f;
     if (oc < OC && !(e.tapsel >> 31)) v = w[(int64_t)oc * ws_o + e.w_off];
-    if (pa.fmt[c]) reinterpret_cast<__bf16*>(pa.wp[c])[((int64_t)(k >> 3) * OCp + oc) * 8 + (k & 7)] = (__bf16)v;   // RNE, as v_cvt_pk_bf16_f32 in the activations' fragments
+    if (pa.fmt[c] == 2) {   // the same RNE split as split3_bf16x8
+        __bf16* o = reinterpret_cast<__bf16*>(pa.wp[c]);
+        const __bf16 hi = (__bf16)v;
+        const float r = v - (float)hi;
+        const __bf16 mid = (__bf16)r;
+        const __bf16 lo = (__bf16)(r - (float)mid);
+        const int64_t base = (((int64_t)(k >> 4) * 6 + ((k >> 3) & 1)) * OCp + oc) * 8 + (k & 7);
+        o[base] = hi; o[base + (int64_t)2 * OCp * 8] = mid; o[base + (int64_t)4 * OCp * 8] = lo;
+    } else if (pa.fmt[c]) reinterpret_cast<__bf16*>(pa.wp[c])[((int64_t)(k >> 3) * OCp + oc) * 8 + (k & 7)] = (__bf16)v;   // RNE, as v_cvt_pk_bf16_f32 in the activations' fragments
     else pa.wp[c][i] = v;
 }
 
@@ -1756,7 +1826,7 @@ __device__ __forceinline__ void wgrad_tile_addr(const WgradArgs& a, int m, int m
 // pitch of 64 words — the same banks; lane (row i, granule q) therefore fetches granule q ^ i of its row (an XOR swizzle on the global side),
 // and row groups are 272 words apart: a fragment read "32 rows x one position" then has a 2-way bank conflict at worst (16 B granules leave 16 of the
 // 64 banks per word phase), which costs ~2 cycles against the 64 of the MFMA it feeds.
-template <int TD, bool BF = false, bool D16 = false>
+template <int TD, int BF = 0, bool D16 = false>   // BF: 0 fp32 MFMA, 1 bf16 products, 2 fp32 on the bf16 pipe (both operands split three ways in registers)
 __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     static_assert(!(BF && D16), "the 16-byte dense staging is built for the fp32 form");
     constexpr int BD = 64 * TD, BJ = 128, P = 65, GP = 272, DREG = D16 ? (BD / 4) * GP : BD * P, TILE = DREG + BJ * P, DR = 16 * TD;   // DR: dense rows DMA'd per wave
@@ -1874,6 +1944,25 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
             const float* gbb[2] = {smem + gbo[0], smem + gbo[1]};
 #pragma unroll
             for (int sb = 0; sb < 4; ++sb) {
+                if constexpr (BF == 2) {
+                    bf16x8 a3[TD][3], b3[2][3];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float t[8];
+                        if (i < TD) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) t[q] = dab[i][16 * sb + q];
+                            split3_bf16x8(t, a3[i < TD ? i : 0]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) t[q] = gbb[i][16 * sb + q];
+                        split3_bf16x8(t, b3[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TD; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) DCV_MFMA_X6(acc[i][j], a3[i], b3[j])
+                } else {
                 bf16x8 a8[TD], b8[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -1892,6 +1981,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
+                }
             }
         } else {
         float af[2][TD], bf[2][2];
@@ -2356,7 +2446,7 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
         pend.c[0].pad0 = n;
     }
     const bool ds = pend.c[0].structured == 2, pt = pend.c[0].patch != 0;
-    const bool bfm = eff_precision() == 1;
+    const int bfm = eff_precision();
 #define DCV_LAUNCH_DMA1(A, B, C_, D, BF_)                                                                                     \
     {                                                                                                                         \
         if (ds && pt) hipLaunchKernelGGL((gather_gemm_dma_kernel<A, B, C_, D, true, true, BF_>), grid, dim3(256), 0, stream, pend); \
@@ -2366,7 +2456,7 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     }
 #define DCV_LAUNCH_DMA(A, B, C_, D)                                                                                           \
     {                                                                                                                         \
-        if (bfm) DCV_LAUNCH_DMA1(A, B, C_, D, true) else DCV_LAUNCH_DMA1(A, B, C_, D, false)                                  \
+        if (bfm == 2) DCV_LAUNCH_DMA1(A, B, C_, D, 2) else if (bfm == 1) DCV_LAUNCH_DMA1(A, B, C_, D, 1) else DCV_LAUNCH_DMA1(A, B, C_, D, 0) \
     }
     if (tc.bn == 128 && tc.bm == 64) DCV_LAUNCH_DMA(2, 1, 2, 2)
     else if (tc.bn == 64 && tc.bm == 128) DCV_LAUNCH_DMA(2, 1, 1, 4)
@@ -2377,8 +2467,8 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
 #undef DCV_LAUNCH_DMA1
     DCV_NOTE_KERNEL("gather_gemm_dma_kernel<%s, %s, %s, %s> (%d x %d tile, %d class%s in one launch%s%s)",
                     tc.bn == 128 ? (tc.bm == 64 ? "2, 1, 2, 2" : "2, 2, 2, 2") : tc.bn == 64 ? (tc.bm == 128 ? "2, 1, 1, 4" : "2, 2, 1, 4") : "1, 2, 1, 4",
-                    ds ? "true" : "false", pt ? "true" : "false", bfm ? "true" : "false", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? (pend.c[0].rag_m0 > 0 ? ", ragged split-K" : ", split-K") : "",
-                    bfm ? ", bf16 products" : "");
+                    ds ? "true" : "false", pt ? "true" : "false", bfm == 2 ? "2" : bfm ? "1" : "0", tc.bn, tc.bm, n, n == 1 ? "" : "es", KS > 1 ? (pend.c[0].rag_m0 > 0 ? ", ragged split-K" : ", split-K") : "",
+                    bfm == 2 ? ", f32x6: fp32 on the bf16 pipe" : bfm ? ", bf16 products" : "");
     DCV_LAUNCH_CHECK();
     if (KS > 1) {
         int64_t tot = 0;
@@ -2390,9 +2480,6 @@ static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& 
     return DCV_OK;
 }
 
-// The generic driver: reduce over `RC` channels of tensor `x` (dims xd) into `OC`
-// channels of tensor `y` (dims yd); classes describe position/tap relations;
-// weight element (oc, rc, kd, kh, kw) lives at oc*ws_o + rc*ws_r + ((kd*KH)+kh)*KW+kw.
 // Which structured K walk (index-table-free, LDS-DMA kernel) a class of a gather op takes: 0 none (table-driven register staging),
 // 2 depth-step order, 1 every step covers 16/T whole channels with all T taps, 3 4x4 inner taps with step = (channel, un-padded depth tap).
 // Decided HERE ONLY: the ragged split-K plan, the packed-weight format and the launch setup all read this one answer.
@@ -2407,6 +2494,12 @@ static int structured_walk(const GatherClass& c, const dcv_dims5& xd, int RC, bo
     return 0;
 }
 
+// bytes per packed weight element: fp32 / bf16 packs fit 4; the three bf16 planes of the fp32-on-bf16 mode need 6
+static inline size_t pack_elem_bytes() { return eff_precision() == 2 ? 6 : sizeof(float); }
+
+// The generic driver: reduce over `RC` channels of tensor `x` (dims xd) into `OC`
+// channels of tensor `y` (dims yd); classes describe position/tap relations;
+// weight element (oc, rc, kd, kh, kw) lives at oc*ws_o + rc*ws_r + ((kd*KH)+kh)*KW+kw.
 static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_dims5& yd, const float* w,
                       int RC, int OC, int64_t ws_o, int64_t ws_r, int KH, int KW,
                       const std::vector<GatherClass>& classes, int act, float slope, int accumulate,
@@ -2588,7 +2681,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         const int KS2 = (KIT + kper - 1) / kper;
         const int slab_mp = Mp - rag_m0;
         // ---- pack weights ----
-        const size_t wp_bytes = align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
+        const size_t wp_bytes = align_up((size_t)KIT * 16 * OCp * pack_elem_bytes(), 256);
         const size_t slab_bytes = KS2 > 1 ? align_up(std::max<size_t>((size_t)KS2 * OCp * slab_mp * sizeof(float), 256), 256) : 0;
         float* wp;
         if (pk_base) {
@@ -2607,7 +2700,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
             packs.ktab[npack] = tab.dev;
             packs.wp[npack] = wp;
             packs.K16[npack] = KIT * 16;
-            packs.fmt[npack] = (will_dma && eff_precision() == 1) ? 1 : 0;
+            packs.fmt[npack] = will_dma ? eff_precision() : 0;   // 0 fp32 [k][OCp], 1 bf16, 2 three bf16 planes: the LDS-DMA kernel instance of that precision reads it
             if (KIT * 16 > packmax) packmax = KIT * 16;
             ++npack;
         }
@@ -2936,7 +3029,7 @@ static size_t gather_ws_bytes(int RC, int OC, int N, const std::vector<GatherCla
         if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
         const int64_t K = (int64_t)RC * T;
         const int KIT = (int)((K + 15) / 16);
-        tot += align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
+        tot += align_up((size_t)KIT * 16 * OCp * pack_elem_bytes(), 256);
         const int64_t M64 = (int64_t)N * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
         const int64_t Mp = (M64 + tc.bm - 1) / tc.bm * tc.bm;
         const int blocks = (int)((OCp / tc.bn) * (Mp / tc.bm));
@@ -2978,7 +3071,7 @@ static size_t gather_pack_bytes(int RC, int OC, const std::vector<GatherClass>& 
         const int T = c.taps[0].n * c.taps[1].n * c.taps[2].n;
         if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
         const int KIT = (int)(((int64_t)RC * T + 15) / 16);
-        tot += align_up((size_t)KIT * 16 * OCp * sizeof(float), 256);
+        tot += align_up((size_t)KIT * 16 * OCp * pack_elem_bytes(), 256);
     }
     return tot;
 }
@@ -3259,20 +3352,24 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     // ... and only the 64-row tile takes it: its 48 row DMAs per 64 MFMAs are what bounds it (cgen.down0 1.351 -> 1.286 ms, gdis.5 0.355 -> 0.353), while
     // the MFMA-bound 128 x 128 tile measured 4-6 % SLOWER with it (the 2-way conflicts of the swizzled fragment reads; profiles/r03_ab_wgrad_d16.txt)
     const bool d16 = !toggles().no_wgrad_d16 && tc.bd == 64 && dd.sw == 1 && dd.w % 4 == 0 && dd.sh % 4 == 0 && dd.sd % 4 == 0 && dd.sn % 4 == 0 && dd.sc % 4 == 0 &&
-                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && eff_precision() != 1;
+                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && eff_precision() == 0;
     {
-        const bool wbf = eff_precision() == 1;
-        if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %s, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf ? "true" : "false", d16 ? "true" : "false", tc.bd, tc.bj, S2, wbf ? ", bf16 products" : "");
+        const int wbf = eff_precision();
+        if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %d, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf, d16 ? "true" : "false", tc.bd, tc.bj, S2,
+                                                  wbf == 2 ? ", f32x6: fp32 on the bf16 pipe" : wbf ? ", bf16 products" : "");
         else DCV_NOTE_KERNEL("wgrad_gemm_kernel (%d x %d tile, %d slabs)", tc.bd, tc.bj, S2);
     }
-    if (dma && a.log2nd >= 0 && eff_precision() == 1) {
-        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((wgrad_dma_kernel<1, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
+    if (dma && a.log2nd >= 0 && eff_precision() == 2) {
+        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, 2>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<1, 2>), dim3(tiles, S2), dim3(256), 0, stream, a);
+    } else if (dma && a.log2nd >= 0 && eff_precision() == 1) {
+        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, 1>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<1, 1>), dim3(tiles, S2), dim3(256), 0, stream, a);
     } else if (dma && a.log2nd >= 0 && d16) {
-        hipLaunchKernelGGL((wgrad_dma_kernel<1, false, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((wgrad_dma_kernel<1, 0, true>), dim3(tiles, S2), dim3(256), 0, stream, a);
     } else if (dma && a.log2nd >= 0) {
-        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, false>), dim3(tiles, S2), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((wgrad_dma_kernel<1, false>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, 0>), dim3(tiles, S2), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((wgrad_dma_kernel<1, 0>), dim3(tiles, S2), dim3(256), 0, stream, a);
     }
     else if (tc.bd == 128 && tc.bj == 32) launch_wgrad<1, 1, 4, 1>(a, tiles, S2, stream);
     else if (tc.bd == 128 && tc.bj == 128) launch_wgrad<2, 2, 2, 2>(a, tiles, S2, stream);

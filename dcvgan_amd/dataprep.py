@@ -65,3 +65,49 @@ def decode_segmentation(labels: torch.Tensor, num_parts: int = 25) -> torch.Tens
     out = torch.empty((B, num_parts, T, H, W), dtype=torch.float32, device=labels.device)
     check(lib().dcv_decode_segmentation(C.c_void_p(labels.data_ptr()), B, T, H, W, num_parts, ptr(out), stream_ptr()), "dcv_decode_segmentation")
     return out
+
+
+class DevicePrefetcher:
+    """Keeps the next training batch on the device one iteration ahead (trainer.py:293-297 does ``batch[...].to(self.device)`` at the top of
+    every iteration: a synchronous, stream-ordered copy that waits for the previous iteration's backward + Adam and serialises 73 MB of
+    PCIe traffic per isogd-depth batch in front of the step).  `source` yields dicts (or tuples) of pinned host tensors — what the
+    reference's DataLoader produces with pin_memory=True (train.py:101-109); the copies run on a stream of their own while the current
+    iteration computes, and ``next()`` hands out DEVICE tensors after making the current stream wait for them, so the trainer's ``.to(device)``
+    is a no-op.  Double-buffered: a batch's memory is reused only after the iteration that consumed it has been enqueued behind it."""
+
+    def __init__(self, source, device):
+        self.it = iter(source)
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._next = None
+        self._preload()
+
+    def _to(self, v):
+        return v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v
+
+    def _preload(self):
+        try:
+            b = next(self.it)
+        except StopIteration:
+            self._next = None
+            return
+        with torch.cuda.stream(self.stream):
+            if isinstance(b, dict):
+                self._next = {k: self._to(v) for k, v in b.items()}
+            else:
+                self._next = type(b)(self._to(v) for v in b)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._next is None:
+            raise StopIteration
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(self.stream)
+        b = self._next
+        for v in (b.values() if isinstance(b, dict) else b):
+            if isinstance(v, torch.Tensor):
+                v.record_stream(cur)
+        self._preload()
+        return b

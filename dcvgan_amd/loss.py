@@ -9,6 +9,48 @@ import torch
 from . import ops, util
 
 
+class HostMirroredLoss(torch.Tensor):
+    """The 0-d device tensor a loss method returns, plus an asynchronous host copy of its value.
+
+    The reference trainer reads every loss with ``loss.cpu().item()`` AFTER the backward pass and the optimiser steps of the same phase
+    (trainer.py:318-328, 355-363).  A plain ``.cpu()`` is a stream-ordered copy: the host would wait for that whole backward + Adam and the
+    GPU would then sit idle while the host enqueues the next phase (measured: +2.2 % per iteration).  The value itself exists as soon as the
+    loss kernels have run, so it is copied to pinned host memory right then, on a side stream behind an event; ``.cpu()`` waits for THAT event
+    only and returns the host value.  Everything else (``+``, ``.backward()``, ``.detach_()``, autograd) is the plain tensor's behaviour; the
+    result of arithmetic on two such tensors carries no mirror and falls back to the ordinary copy."""
+
+    _side = {}
+
+    @staticmethod
+    def wrap(t: torch.Tensor) -> torch.Tensor:
+        if not t.is_cuda:
+            return t
+        dev = t.device
+        side = HostMirroredLoss._side.get(dev.index)
+        if side is None:
+            side = HostMirroredLoss._side[dev.index] = torch.cuda.Stream(dev)
+        out = t.as_subclass(HostMirroredLoss)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        host = torch.empty((), dtype=t.dtype, pin_memory=True)
+        src = t.detach()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            host.copy_(src, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        src.record_stream(side)
+        out._mirror = (host, done)
+        return out
+
+    def cpu(self, *args, **kwargs):
+        m = getattr(self, "_mirror", None)
+        if m is None or args or kwargs:
+            return super().cpu(*args, **kwargs)
+        m[1].synchronize()
+        return m[0].clone()
+
+
 class Loss(object):
     __metaclass__ = ABCMeta
 
@@ -29,11 +71,11 @@ class AdversarialLoss(Loss):
         self.device = util.current_device()
 
     def compute_dis_loss(self, y_real, y_fake):
-        return ops.gan_loss(y_real, ops.KIND_BCE_ONES) + ops.gan_loss(y_fake, ops.KIND_BCE_ZEROS)
+        return HostMirroredLoss.wrap(ops.gan_loss(y_real, ops.KIND_BCE_ONES) + ops.gan_loss(y_fake, ops.KIND_BCE_ZEROS))
 
     def compute_gen_loss(self, y_fake_i, y_fake_v, y_fake_g):
-        return (ops.gan_loss(y_fake_i, ops.KIND_BCE_ONES) + ops.gan_loss(y_fake_v, ops.KIND_BCE_ONES)
-                + ops.gan_loss(y_fake_g, ops.KIND_BCE_ONES))
+        return HostMirroredLoss.wrap(ops.gan_loss(y_fake_i, ops.KIND_BCE_ONES) + ops.gan_loss(y_fake_v, ops.KIND_BCE_ONES)
+                                     + ops.gan_loss(y_fake_g, ops.KIND_BCE_ONES))
 
 
 class HingeLoss(Loss):
@@ -45,7 +87,7 @@ class HingeLoss(Loss):
         self.device = util.current_device()
 
     def compute_dis_loss(self, y_real, y_fake):
-        return ops.gan_loss(y_real, ops.KIND_HINGE_REAL) + ops.gan_loss(y_fake, ops.KIND_HINGE_FAKE)
+        return HostMirroredLoss.wrap(ops.gan_loss(y_real, ops.KIND_HINGE_REAL) + ops.gan_loss(y_fake, ops.KIND_HINGE_FAKE))
 
     def compute_gen_loss(self, y_fake_i, y_fake_v, y_fake_g):
-        return ops.gan_loss(y_fake_i, ops.KIND_SOFTPLUS_NEG) + ops.gan_loss(y_fake_v, ops.KIND_SOFTPLUS_NEG)
+        return HostMirroredLoss.wrap(ops.gan_loss(y_fake_i, ops.KIND_SOFTPLUS_NEG) + ops.gan_loss(y_fake_v, ops.KIND_SOFTPLUS_NEG))

@@ -139,11 +139,13 @@ class GradBucket:
     _force_layout = False
 
     def add(self, params: Iterable[torch.nn.Parameter]):
-        if self._flat is not None:
-            raise NativeError("GradBucket.add after the flat buffer was laid out")
+        have = {id(p) for p in self.params}
         for p in params:
+            if id(p) in have:
+                continue              # already a member (a wrapper built around a bucket that was filled by hand)
             self.params.append(p)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._mark))
+            self._flat = None         # a new member: the buffer is laid out again at the next gradient (existing .grad slices are copied over)
 
     @torch.no_grad()
     def reduce(self, force: bool = False):

@@ -130,9 +130,10 @@ class StepRunner:
             o["idis"].step(); o["vdis"].step(); o["gdis"].step()
         else:
             loss_dis.detach_()
-        out = {"loss_idis": loss_idis.detach(), "loss_vdis": loss_vdis.detach(), "loss_gdis": loss_gdis.detach()}
-        if self.sync_losses:
-            out = {k: v.cpu().item() for k, v in out.items()}
+        if self.sync_losses:   # trainer.py:326-328 — on the loss objects themselves, as the reference reads them (they carry a host mirror: loss.HostMirroredLoss)
+            out = {"loss_idis": loss_idis.cpu().item(), "loss_vdis": loss_vdis.cpu().item(), "loss_gdis": loss_gdis.cpu().item()}
+        else:
+            out = {"loss_idis": loss_idis.detach(), "loss_vdis": loss_vdis.detach(), "loss_gdis": loss_gdis.detach()}
         del y_real, y_fake, xg_fake, xc_fake, loss_dis
         # ---- generator phase (trainer.py:338-363) ----
         ggen.train(); cgen.train()
@@ -146,5 +147,5 @@ class StepRunner:
             o["ggen"].step(); o["cgen"].step(); o["ggen"].step()  # ggen twice — trainer.py:357-359
         else:
             loss_gen.detach_()
-        out["loss_gen"] = loss_gen.detach().cpu().item() if self.sync_losses else loss_gen.detach()
+        out["loss_gen"] = loss_gen.cpu().item() if self.sync_losses else loss_gen.detach()     # trainer.py:363
         return out

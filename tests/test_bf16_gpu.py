@@ -139,3 +139,80 @@ def test_precision_is_a_per_module_switch():
         assert layers.geom_of(a).mfma == 0
     finally:
         native.set_precision("fp32")
+
+
+# --------------------------------------------------------------------------- #
+# fp32 emulated on the bf16 matrix pipe ("f32x6", dcv_set_precision(2); round 4, experimental — never the default)
+# --------------------------------------------------------------------------- #
+@pytest.fixture()
+def f32x6(request):
+    from dcvgan_amd import native
+    native.lib()
+    native.set_precision("f32x6")
+    yield torch.device("cuda:0")
+    native.set_precision("fp32")
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_f32x6(f32x6, case):
+    """Every operand is split EXACTLY into three bf16 pieces and the six products of total order <= 2 are accumulated in fp32: the results are
+    fp32-grade — held to 2e-6 relative L2 against an fp64 evaluation (measured ~2e-7, the native fp32 MFMA kernels' own level; the bf16-product
+    mode sits at 3e-3) for forward, data gradient and weight gradient, on every geometry that takes the LDS-DMA kernels."""
+    from dcvgan_amd import native, ops
+    dev = f32x6
+    name, tr, nd, cin, cout, k, s, p, sp, n = case
+    g = torch.Generator().manual_seed(hash(name) % 10000)
+    s_t = (s,) * nd if isinstance(s, int) else s
+    p_t = (p,) * nd if isinstance(p, int) else p
+    w = (torch.randn(((cin, cout) if tr else (cout, cin)) + (k,) * nd, generator=g) * 0.2).requires_grad_(True)
+    x = torch.randn((n, cin) + sp, generator=g).requires_grad_(True)
+    fn = {(False, 2): F.conv2d, (False, 3): F.conv3d, (True, 2): F.conv_transpose2d}[(tr, nd)]
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    y_ref = fn(x64, w64, None, s_t, p_t)
+    cot = torch.randn(y_ref.shape, generator=g)
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * cot.double()).sum(), [x64, w64])
+    xd, wd = x.detach().to(dev).requires_grad_(True), w.detach().to(dev).requires_grad_(True)
+    y = ops.conv(xd, wd, ops.conv_geom(wd, s_t, p_t, tr))
+    kernel = native.lib().dcv_debug_last_kernel().decode()
+    gx, gw = torch.autograd.grad((y * cot.to(dev)).sum(), [xd, wd])
+    errs = [rel(y, y_ref), rel(gx, gx_ref), rel(gw, gw_ref)]
+    assert max(errs) < 2e-6, (name, kernel, errs)
+    if "dma" in kernel:
+        assert "f32x6" in kernel, kernel
+
+
+def test_pack_precision_stamp():
+    """A caller-owned packed-weight buffer is stamped with the precision it was packed for (dcv_wpack.precision): the same weight tensor run at fp32,
+    then f32x6, then fp32 again gives the fp32 result both times (the cache keeps one pack per precision), and a ready pack handed to a call of
+    another precision is refused by the library itself (DCV_EINVAL), not read."""
+    import ctypes as C
+    from dcvgan_amd import native, ops
+    from dcvgan_amd.native import WPack, check, dims5, lib, ptr, stream_ptr
+    dev = torch.device("cuda:0")
+    g0 = torch.Generator().manual_seed(11)
+    w = (torch.randn(128, 16, 4, 4, generator=g0) * 0.1).to(dev)
+    x = torch.randn(9, 16, 16, 16, generator=g0).to(dev)
+    with torch.no_grad():
+        y1 = ops.conv(x, w, ops.conv_geom(w, (2, 2), (1, 1), False))
+        native.set_precision("f32x6")
+        try:
+            y2 = ops.conv(x, w, ops.conv_geom(w, (2, 2), (1, 1), False))
+        finally:
+            native.set_precision("fp32")
+        y3 = ops.conv(x, w, ops.conv_geom(w, (2, 2), (1, 1), False))
+    assert torch.equal(y1, y3) and rel(y2, y1) < 1e-6
+    L = lib()
+    g = ops.conv_geom(w, (2, 2), (1, 1), False)
+    y = torch.empty_like(y1)
+    xd, yd = dims5(x), dims5(y)
+    nb = L.dcv_conv_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0)
+    buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+    ws = torch.empty(L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0) + 256, dtype=torch.uint8, device=dev)
+    pk = WPack(buf.data_ptr(), nb, 0, 1)
+    check(L.dcv_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, 0.0, C.byref(pk), ptr(ws), ws.numel(), stream_ptr()), "pack")
+    assert torch.equal(y, y1)
+    pk.ready = 1
+    g_x6 = ops.conv_geom(w, (2, 2), (1, 1), False, "f32x6")
+    n0 = native.launch_count()
+    rc = L.dcv_conv_forward(C.byref(g_x6), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, 0.0, C.byref(pk), ptr(ws), ws.numel(), stream_ptr())
+    assert rc == -1 and b"dcv_wpack.precision" in L.dcv_last_error() and native.launch_count() == n0
