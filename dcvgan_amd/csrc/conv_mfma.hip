@@ -837,19 +837,29 @@ __global__ __launch_bounds__(256, (BF == 2 ? 3 : 4)) void gather_gemm_dma_kernel
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
                     a8[i][pc] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(wt) + 16 * ((pc * 2 + lhi) * BN + (woc * TOC + i) * 32 + l31));
+            float tb[TM][8];
 #pragma unroll
-            for (int jj = 0; jj < TM; ++jj) {
-                float t[8];
+            for (int jj = 0; jj < TM; ++jj)
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    t[q] = PATCH ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xt) + (fbb[PATCH ? jj : 0] + koff8[PATCH ? q : 0]))
-                                 : xt[(8 * lhi + q) * BM + (wm * TM + jj) * 32 + l31];
-                split3_bf16x8(t, b8[jj]);
+                    tb[jj][q] = PATCH ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xt) + (fbb[PATCH ? jj : 0] + koff8[PATCH ? q : 0]))
+                                      : xt[(8 * lhi + q) * BM + (wm * TM + jj) * 32 + l31];
+            // position column jj + 1 is split (44 VALU operations) in the shadow of column jj's 6 TOC MFMAs: an MFMA holds the matrix pipe for 32
+            // cycles and the vector issue for 8 of them, so ~4 operations behind each one issue for free; only column 0's split is exposed
+            split3_bf16x8(tb[0], b8[0]);
+#pragma unroll
+            for (int jj = 0; jj < TM; ++jj) {
+                if (jj + 1 < TM) split3_bf16x8(tb[jj + 1 < TM ? jj + 1 : 0], b8[jj + 1 < TM ? jj + 1 : 0]);
+#pragma unroll
+                for (int i = 0; i < TOC; ++i) DCV_MFMA_X6(acc[i][jj], a8[i], b8[jj])
+                if (jj + 1 < TM) {
+#pragma unroll
+                    for (int q = 0; q < 6 * TOC; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                }
             }
-#pragma unroll
-            for (int i = 0; i < TOC; ++i)
-#pragma unroll
-                for (int jj = 0; jj < TM; ++jj) DCV_MFMA_X6(acc[i][jj], a8[i], b8[jj])
             __builtin_amdgcn_s_setprio(0);
             continue;
         } else if constexpr (BF == 1) {

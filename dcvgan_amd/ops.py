@@ -110,9 +110,9 @@ class _PackCache:
         self.entries = {}
 
     def get(self, w, which, g, xd_t, yd_t, xd, yd):
-        key = (which, g.key(), tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
+        prec = lib().dcv_conv_effective_precision(C.byref(g))                              # the packed FORMAT (and size) depends on it; the library checks the stamp too
+        key = (which, g.key(), prec, tuple(xd_t.shape), tuple(xd_t.stride()), tuple(yd_t.shape), tuple(yd_t.stride()))   # the K order depends on the layout
         e = self.entries.get(key)
-        prec = lib().dcv_conv_effective_precision(C.byref(g))                              # the packed FORMAT depends on it; the library checks the stamp too
         stamp = (w._version, w.data_ptr(), prec)
         if _POISON:
             # debug builds of the tests: edits autograd cannot see (`p.data.normal_()`, raw-pointer writes) do not bump the version;

@@ -26,7 +26,7 @@ ap.add_argument("--csv", default="")
 ap.add_argument("--filter", default="")
 ap.add_argument("--plan", default="")
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6"])
 a = ap.parse_args()
 cfg = CONFIGS[a.config]
 B = a.batch or cfg.batchsize
