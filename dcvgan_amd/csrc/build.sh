@@ -10,12 +10,12 @@ OUT="$HERE/../libdcvgan_hip.so"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p "$HERE/obj"
 pids=()
-for f in conv_mfma elementwise; do
+for f in conv_mfma elementwise conv_cl16 cl_elementwise; do
   if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/dcv_common.h" -nt "$HERE/obj/$f.o" ] || [ "$ROOT/include/dcvgan_hip.h" -nt "$HERE/obj/$f.o" ]; then
     hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/conv_mfma.o" "$HERE/obj/elementwise.o"
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || exit 1; }; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/conv_mfma.o" "$HERE/obj/elementwise.o" "$HERE/obj/conv_cl16.o" "$HERE/obj/cl_elementwise.o"
 echo "built $OUT"

@@ -1,0 +1,888 @@
+// bf16 channels-last ("CL16") implicit-GEMM convolutions for gfx950 on v_mfma_f32_32x32x16_bf16 — the bf16 DATA path of
+// BASELINE configs[2] ("surreal-depth1, bf16 MFMA") and configs[4] ("fp16 MFMA"; bf16 has the same MFMA rate and fragment path and
+// fp32's exponent range).  The fp32 NCDHW kernels of conv_mfma.hip stay the default and the parity path; here
+//
+//   * activations and their gradients live in HBM as bf16 with the CHANNEL innermost (memory order n, d, h, w, c; the channel
+//     stride is 1 and the pixel pitch `ldc` a multiple of 8, so a concatenation is two channel ranges of one buffer),
+//   * weights are fp32 masters in torch layout, packed per optimiser step into bf16 K-major tiles,
+//   * accumulation, BatchNorm statistics, weight gradients and the optimiser are fp32.
+//
+// With K = (tap, channel) contiguous per pixel an MFMA operand fragment (8 consecutive k of one row) is ONE 16-byte LDS read and
+// one 16-byte LDS-DMA granule per lane, for every stride / padding / tap count: the gathering is done by per-lane global
+// addresses, zero padding by the buffer range check.
+//
+//  gather GEMM   Y[m, oc] = sum_{t, c} X[pos(m, t), c] * Wp[t, c, oc]     forward, data gradient (one launch, z = stride-parity class)
+//      MFMA A = weights (rows = oc), B = activations (cols = positions): an accumulator register quad holds 4 consecutive oc of one
+//      position = one 8-byte channels-last store.
+//  wgrad GEMM    R[t, dc, gc] = sum_m D[m, dc] * G[pos(m, t), gc]          K = positions: both operands are read from their
+//      [position][channel] LDS images with the transposing read ds_read_b64_tr_b16.
+#include "dcv_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace dcv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+extern thread_local char g_last_kernel[160];
+
+// --------------------------------------------------------------------------- //
+// geometry: one "class" = the output positions that share a tap set (all of them for a direct gather; one stride-parity class
+// of a scatter-form op), as in conv_mfma.hip
+// --------------------------------------------------------------------------- //
+struct ClDim {
+    int32_t n;                 // taps along this dim (<= 4)
+    int32_t mul, base, size;   // gathered coordinate = o * mul + base + delta[u], valid in [0, size)
+    int32_t delta[4];
+    int32_t kidx[4];           // filter index of tap u
+};
+struct ClClass {
+    int32_t o_ext[3], out_mul[3], out_off[3];
+    ClDim t[3];
+};
+
+static std::vector<ClClass> cl_direct_classes(const int k[3], const int s[3], const int p[3], const int o_ext[3], const int in_ext[3]) {
+    ClClass c;
+    memset(&c, 0, sizeof(c));
+    for (int d = 0; d < 3; ++d) {
+        c.o_ext[d] = o_ext[d]; c.out_mul[d] = 1; c.out_off[d] = 0;
+        c.t[d].n = k[d]; c.t[d].mul = s[d]; c.t[d].base = -p[d]; c.t[d].size = in_ext[d];
+        for (int u = 0; u < k[d]; ++u) { c.t[d].delta[u] = u; c.t[d].kidx[u] = u; }
+    }
+    return {c};
+}
+// scatter form (conv data gradient / transposed conv forward): out[o] += src[i] w[k] with o = i s - p + k  =>  per class cls = o mod s:
+// k = k0 + u s, i = (o + p - k) / s = o' + q - u  (o = o' s + cls)
+static std::vector<ClClass> cl_scatter_classes(const int k[3], const int s[3], const int p[3], const int out_ext[3], const int in_ext[3]) {
+    std::vector<ClClass> out;
+    for (int cd = 0; cd < s[0]; ++cd)
+        for (int ch = 0; ch < s[1]; ++ch)
+            for (int cw = 0; cw < s[2]; ++cw) {
+                const int cls[3] = {cd, ch, cw};
+                ClClass c;
+                memset(&c, 0, sizeof(c));
+                for (int d = 0; d < 3; ++d) {
+                    c.o_ext[d] = (out_ext[d] - cls[d] + s[d] - 1) / s[d];
+                    c.out_mul[d] = s[d];
+                    c.out_off[d] = cls[d];
+                    const int k0 = (cls[d] + p[d]) % s[d];
+                    const int q = (cls[d] + p[d] - k0) / s[d];
+                    c.t[d].mul = 1; c.t[d].base = q; c.t[d].size = in_ext[d];
+                    int u = 0;
+                    for (int kk = k0; kk < k[d] && u < 4; kk += s[d], ++u) { c.t[d].delta[u] = -u; c.t[d].kidx[u] = kk; }
+                    c.t[d].n = u;
+                }
+                out.push_back(c);
+            }
+    return out;
+}
+
+static inline int pad8(int c) { return (c + 7) / 8 * 8; }
+// K granularity of a gathered operand with C channels: thin (C <= 8: one 16-byte granule per tap, 4 taps per 32-deep K step) or
+// whole 32-channel blocks
+static inline bool cl_thin(int C) { return C <= 8; }
+static inline int cl_cp(int C) { return cl_thin(C) ? 8 : (C + 31) / 32 * 32; }
+
+// --------------------------------------------------------------------------- //
+// gather GEMM
+// --------------------------------------------------------------------------- //
+struct ClGatherArgs {
+    const __bf16* x;
+    __bf16* y;
+    const __bf16* wp;            // [step][OCp][32] bf16
+    int32_t M, OCp, nsteps, T;   // positions, padded output channels (multiple of the tile's), 32-deep K steps, taps
+    int32_t cblk, y_c;           // 32-channel blocks per tap (0 = thin); channels to store (destination channels, multiple of 4)
+    int32_t x_cmax, pad0;        // bytes of one pixel's valid channels (granules past it are padding)
+    FastDiv div_sp, div_hw, div_w;
+    ClDim td, th, tw;
+    int64_t x_sn, y_sn;          // element strides
+    int32_t x_sd, x_sh, x_sw;
+    int32_t y_sd, y_sh, y_sw, y_off;   // output strides incl. the class multiplier, class offset
+    int32_t act, accumulate;
+    float slope, pad1;
+    uint32_t x_bytes, y_bytes;   // buffer extents (range check = padding and guard)
+    int32_t toff[64];            // byte offset of tap t relative to the position's base pixel
+    int32_t tsel[64];            // ud | uh << 2 | uw << 4
+};
+struct ClGatherPack {
+    ClGatherArgs c[4];
+    int32_t ncls, tiles_oc, tiles_m, pad;
+};
+
+__device__ __forceinline__ float cl_act(float v, int act, float slope) {
+    if (act == DCV_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    if (act == DCV_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t cl_dim_mask(const ClDim& t, int o) {
+    uint32_t m = 0;
+    const int p0 = o * t.mul + t.base;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m |= ((unsigned)(p0 + t.delta[u]) < (unsigned)t.size && u < t.n) ? (1u << u) : 0u;
+    return m;
+}
+
+// 256 threads = 4 waves laid out WOC x WM, each wave TOC x TM MFMA tiles of 32 x 32; BN = 32 TOC WOC output channels, BM = 32 TM WM
+// positions, K step 32.  LDS: two stages of [BM rows][64 B] activations + [BN rows][64 B] weights; the four 16-byte chunks of a
+// row are XOR-swizzled with (row >> 2) & 3 on the DMA's SOURCE side (an LDS-DMA lands lane-linear), which makes the fragment
+// reads "32 rows x one chunk" (ds_read_b128) conflict-free.
+template <int TOC, int TM, int WOC, int WM, bool THIN>
+__global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pack) {
+    constexpr int BN = 32 * TOC * WOC, BM = 32 * TM * WM;
+    constexpr int XPT = BM * 4 / 256, WPT = (BN * 4 + 255) / 256;
+    constexpr int XB = BM * 64, WB = BN * 64, STAGE = XB + WB;
+    static_assert(WOC * WM == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (THIN ? 256 : 0)];
+
+    // workgroup -> (class, oc tile, m tile): ids 8 apart (the same XCD's L2) share the gathered operand
+    const unsigned grp = (unsigned)(pack.tiles_oc * pack.ncls), loc = blockIdx.x >> 3;
+    const unsigned gi = loc % grp;
+    const int m_t = (int)((loc / grp) * 8 + (blockIdx.x & 7));
+    const int oc_t = (int)(gi % (unsigned)pack.tiles_oc);
+    const ClGatherArgs& a = pack.c[gi / (unsigned)pack.tiles_oc];
+    const int m0 = m_t * BM, oc0 = oc_t * BN;
+    if (m0 >= a.M) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int woc = wave / WM, wm = wave % WM;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 0x80000000u, 0x00020000);
+    // thin operands: a lane's granule is one TAP of the step, so the tap offset is per lane: table in LDS (one array: see the LDS-DMA tracking
+    // note in conv_mfma.hip), read one step ahead of its use
+    const int32_t* toff_l = reinterpret_cast<const int32_t*>(smem + 2 * STAGE);
+    if constexpr (THIN) {
+        if (tid < 64) reinterpret_cast<int32_t*>(smem + 2 * STAGE)[tid] = a.toff[tid];
+        __syncthreads();
+    }
+
+    // ---- staging roles: granule g = tid + 256 s -> row g >> 2, physical chunk g & 3, logical chunk (g & 3) ^ ((row >> 2) & 3)
+    uint32_t xbase[XPT];
+    uint64_t xmask[XPT];
+    int xchunk[XPT];
+#pragma unroll
+    for (int s = 0; s < XPT; ++s) {
+        const int g = tid + 256 * s, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
+        const int m = m0 + row;
+        xchunk[s] = c;
+        uint64_t vm = 0;
+        uint32_t base = 0;
+        if (m < a.M) {
+            const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+            uint32_t r = (uint32_t)m - n * a.div_sp.div;
+            const uint32_t od = fdiv(r, a.div_hw);
+            r -= od * a.div_hw.div;
+            const uint32_t oh = fdiv(r, a.div_w);
+            const uint32_t ow = r - oh * a.div_w.div;
+            const uint32_t md = cl_dim_mask(a.td, (int)od), mh = cl_dim_mask(a.th, (int)oh), mw = cl_dim_mask(a.tw, (int)ow);
+            // signed pixel offset of tap (0,0,0)'s base; every VALID tap's offset makes the sum non-negative
+            const int64_t e = (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base) * a.x_sd + (int64_t)((int)oh * a.th.mul + a.th.base) * a.x_sh +
+                              (int64_t)((int)ow * a.tw.mul + a.tw.base) * a.x_sw;
+            base = (uint32_t)(2 * e) + (THIN ? 0u : (uint32_t)(16 * c));
+            for (int t = 0; t < a.T; ++t) {
+                const uint32_t sel = (uint32_t)a.tsel[t];
+                const uint32_t ok = (md >> (sel & 3)) & (mh >> ((sel >> 2) & 3)) & (mw >> ((sel >> 4) & 3)) & 1u;
+                vm |= (uint64_t)ok << t;
+            }
+            if (!THIN && 16 * c >= a.x_cmax) vm = 0;     // (never happens: whole 32-channel blocks) kept for symmetry
+        }
+        xbase[s] = base;
+        xmask[s] = vm;
+    }
+    uint32_t wvo[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int g = tid + 256 * j, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
+        wvo[j] = (uint32_t)(((oc0 + row) * 32 + c * 8) * 2);
+    }
+    const uint32_t wstep = (uint32_t)a.OCp * 64u;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CL_ISSUE(STEP, BUF)                                                                                                   \
+    {                                                                                                                         \
+        const int st_ = (STEP);                                                                                               \
+        char* xb_ = smem + (BUF) * STAGE;                                                                                     \
+        char* wb_ = xb_ + XB;                                                                                                 \
+        if constexpr (THIN) {                                                                                                 \
+            _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                                 \
+                const int t_ = st_ * 4 + xchunk[s];                                                                           \
+                const uint32_t ok_ = (uint32_t)(xmask[s] >> t_) & 1u;                                                         \
+                const uint32_t vo_ = ok_ ? xbase[s] + (uint32_t)toff_l[t_ & 63] : 0xffffffffu;                               \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, vo_, 0, 0, 0); \
+            }                                                                                                                 \
+        } else {                                                                                                              \
+            const int tap_ = st_ / a.cblk, cb_ = st_ - tap_ * a.cblk;                                                         \
+            const uint32_t to_ = (uint32_t)a.toff[tap_];                                                                      \
+            _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                                 \
+                const uint32_t ok_ = (uint32_t)(xmask[s] >> tap_) & 1u;                                                       \
+                const uint32_t vo_ = ok_ ? xbase[s] + to_ : 0xffffffffu;                                                      \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, vo_, cb_ * 64, 0, 0); \
+            }                                                                                                                 \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                       \
+            if ((BN * 4) % 256 == 0 || wave * 64 + 256 * j < BN * 4)                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(wb_ + (j * 256 + wave * 64) * 16), 16, wvo[j], st_ * wstep, 0, 0); \
+    }
+#else
+#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; }
+#endif
+
+    f32x16 acc[TOC][TM];
+#pragma unroll
+    for (int i = 0; i < TOC; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row r, K16 half s, lane half lhi -> logical chunk 2 s + lhi, physical chunk ^ ((r >> 2) & 3)
+    uint32_t aoff[TOC][2], boff[TM][2];
+#pragma unroll
+    for (int i = 0; i < TOC; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = (woc * TOC + i) * 32 + l31;
+            aoff[i][s] = (uint32_t)(XB + row * 64 + (((2 * s + lhi) ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row = (wm * TM + j) * 32 + l31;
+            boff[j][s] = (uint32_t)(row * 64 + (((2 * s + lhi) ^ ((row >> 2) & 3)) << 4));
+        }
+
+    const int nst = a.nsteps;
+    CL_ISSUE(0, 0)
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < nst) CL_ISSUE(st + 1, buf ^ 1)
+        const char* sb = smem + buf * STAGE;
+        bf16x8 a8[TOC][2], b8[TM][2];
+#pragma unroll
+        for (int i = 0; i < TOC; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) a8[i][s] = *reinterpret_cast<const bf16x8*>(sb + aoff[i][s]);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) b8[j][s] = *reinterpret_cast<const bf16x8*>(sb + boff[j][s]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i][s], b8[j][s], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- epilogue: 4 consecutive output channels of one position per register quad -> one 8-byte store
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    const int act = a.act;
+    const float slope = a.slope;
+    const bool accum = a.accumulate != 0;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + (wm * TM + j) * 32 + l31;
+        uint32_t vo = 0xffffffffu;
+        if (m < a.M) {
+            const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+            uint32_t r = (uint32_t)m - n * a.div_sp.div;
+            const uint32_t od = fdiv(r, a.div_hw);
+            r -= od * a.div_hw.div;
+            const uint32_t oh = fdiv(r, a.div_w);
+            const uint32_t ow = r - oh * a.div_w.div;
+            vo = (uint32_t)(2 * ((int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw + a.y_off));
+        }
+#pragma unroll
+        for (int i = 0; i < TOC; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int oc = oc0 + (woc * TOC + i) * 32 + 8 * q + 4 * lhi;
+                const uint32_t v2 = (oc < a.y_c && vo != 0xffffffffu) ? vo + (uint32_t)(2 * oc) : 0xffffffffu;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (accum) {
+                    const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(yrs, v2, 0, 0);
+                    v[0] += __builtin_bit_cast(float, old[0] << 16); v[1] += __builtin_bit_cast(float, old[0] & 0xffff0000u);
+                    v[2] += __builtin_bit_cast(float, old[1] << 16); v[3] += __builtin_bit_cast(float, old[1] & 0xffff0000u);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cl_act(v[e], act, slope);
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                const f32x2_ p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
+                u32x2 o;
+                o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
+                o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                __builtin_amdgcn_raw_buffer_store_b64(o, yrs, v2, 0, 0);
+            }
+    }
+}
+#undef CL_ISSUE
+
+// Wp[cls][step][OCp][32]: thick: step = tap * cblk + cb, k = channel cb * 32 + kk;  thin: step covers taps 4 step .. 4 step + 3, k = (tap & 3) * 8 + channel
+struct ClPackArgs {
+    __bf16* wp[4];
+    int32_t nsteps[4], T[4];
+    int32_t kidx[4][64];      // filter index (kd * KH + kh) * KW + kw of tap t
+    int32_t ncls, OC, OCp, C, cblk;   // cblk = 0: thin
+    int32_t pad;
+    int64_t ws_o, ws_r;       // w[oc * ws_o + c * ws_r + kidx]
+};
+__global__ __launch_bounds__(256) void cl_pack_kernel(const float* __restrict__ w, const ClPackArgs pa) {
+    const int cls = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)pa.nsteps[cls] * pa.OCp * 32;
+    if (i >= tot) return;
+    const int kk = (int)(i & 31), oc = (int)((i >> 5) % pa.OCp), step = (int)((i >> 5) / pa.OCp);
+    int tap, c;
+    if (pa.cblk == 0) { tap = step * 4 + (kk >> 3); c = kk & 7; }
+    else { tap = step / pa.cblk; c = (step % pa.cblk) * 32 + kk; }
+    float v = 0.f;
+    if (oc < pa.OC && c < pa.C && tap < pa.T[cls]) v = w[(int64_t)oc * pa.ws_o + (int64_t)c * pa.ws_r + pa.kidx[cls][tap]];
+    pa.wp[cls][i] = (__bf16)v;
+}
+
+// --------------------------------------------------------------------------- //
+// weight gradient.  R[t][dc][gc] = sum_m D[m][dc] * G[pos(m, t)][gc]:  D = the tensor on whose position grid the sum runs ("dense": dy of a
+// conv, x of a transposed conv), G the gathered one at coordinate m * stride - pad + tap.  The reduction runs over positions, so BOTH MFMA operands
+// need "8 consecutive positions of one channel" per lane while memory (and the LDS image an LDS-DMA produces) is [position][channel]: the fragments
+// are read with ds_read_b64_tr_b16, which transposes 4 x 16 blocks on the way out of LDS.
+//   tile: 128 dense channels x 128 "virtual gathered columns" = (tap-in-tile, channel) pairs: GCB = min(GCp, 128) channels of 128 / GCB taps, so a thin
+//   operand (8 padded channels) shares one tile among 16 taps and a 64-channel one among 2;
+//   K step = 32 positions: D tile [32][256 B] + G tile [32][256 B], the sixteen 16-byte chunks of a row XOR-swizzled with
+//   f(row) = ((row & 3) << 2) | ((row >> 2) & 3) on the DMA's source side: the transposing reads are then conflict-free;
+//   D must be pixel-linear (address = m * pitch), so its per-lane DMA offsets never change and the step walks on the scalar offset; G's per-position
+//   base offset and per-tap validity come from a table one small kernel fills per call (16 bytes per position);
+//   grid.y splits the positions; partial tiles go to fp32 slabs summed in a fixed order (bitwise reproducible) by cl_wgrad_reduce_kernel, which also
+//   scatters into the torch weight layout.
+// --------------------------------------------------------------------------- //
+struct ClPosEntry {
+    int32_t gbase;      // byte offset of G at (n, d s - p, h s - p, w s - p), signed
+    uint32_t rsv;
+    uint64_t vmask;     // bit t: tap t in range for this position
+};
+struct ClPosArgs {
+    ClPosEntry* tab;
+    int32_t M, T, KH, KW;
+    FastDiv div_sp, div_hw, div_w;
+    int32_t s[3], p[3], k[3], gext[3];
+    int64_t g_sn;
+    int32_t g_sd, g_sh, g_sw, pad;
+};
+__global__ __launch_bounds__(256) void cl_postab_kernel(const ClPosArgs a) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= a.M) return;
+    const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+    uint32_t r = (uint32_t)m - n * a.div_sp.div;
+    const uint32_t od = fdiv(r, a.div_hw);
+    r -= od * a.div_hw.div;
+    const uint32_t oh = fdiv(r, a.div_w);
+    const uint32_t ow = r - oh * a.div_w.div;
+    const int c0[3] = {(int)od * a.s[0] - a.p[0], (int)oh * a.s[1] - a.p[1], (int)ow * a.s[2] - a.p[2]};
+    uint64_t vm = 0;
+    for (int t = 0; t < a.T; ++t) {
+        const int kd = t / (a.KH * a.KW), kh = (t / a.KW) % a.KH, kw = t % a.KW;
+        const bool ok = (unsigned)(c0[0] + kd) < (unsigned)a.gext[0] && (unsigned)(c0[1] + kh) < (unsigned)a.gext[1] && (unsigned)(c0[2] + kw) < (unsigned)a.gext[2];
+        vm |= (uint64_t)ok << t;
+    }
+    ClPosEntry e;
+    e.gbase = (int32_t)(2 * ((int64_t)n * a.g_sn + (int64_t)c0[0] * a.g_sd + (int64_t)c0[1] * a.g_sh + (int64_t)c0[2] * a.g_sw));
+    e.rsv = 0;
+    e.vmask = vm;
+    a.tab[m] = e;
+}
+
+struct ClWgradArgs {
+    const __bf16* d;
+    const __bf16* g;
+    const ClPosEntry* tab;
+    float* slab;                 // [split][tile][128][128]
+    int32_t M, chunk;            // positions; positions per split (multiple of 32)
+    int32_t d_pitch2, d_cbytes;  // dense pixel pitch in bytes; bytes of a pixel's (padded) valid channels
+    int32_t g_cbytes, T;         // same for the gathered tensor; taps
+    int32_t tiles_d, gblocks;    // dense-channel tiles; 128-channel blocks of the gathered tensor (1 when GCp <= 128)
+    int32_t gcb8, ntpt;          // 16-byte chunks per tap in a tile (GCB / 8); taps per tile (128 / GCB)
+    uint32_t d_bytes, g_bytes;
+    int32_t toff[64];            // byte offset of tap t relative to a position's gbase
+};
+
+__device__ __forceinline__ int cl_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
+    constexpr int IMG = 32 * 256, STAGE = 2 * IMG;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wd = wave >> 1, wj = wave & 1;
+    const int d_t = blockIdx.x % a.tiles_d, j_t = blockIdx.x / a.tiles_d;
+    const int tg = j_t / a.gblocks, gb = j_t - tg * a.gblocks;
+    const int m_begin = blockIdx.y * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int nst = m_end > m_begin ? (m_end - m_begin + 31) / 32 : 0;
+
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.d), 0, a.d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.g), 0, a.g_bytes, 0x00020000);
+
+    // staging roles: granule g = tid + 256 s -> row g >> 4 (position of the step), physical chunk g & 15, logical chunk ^ f(row)
+    uint32_t dvo[2];
+    int32_t gadd[2];
+    uint32_t gtap[2];
+    int rowi[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int gq = tid + 256 * s, row = gq >> 4, q = (gq & 15) ^ cl_swz(row);
+        rowi[s] = row;
+        const int dcb = (d_t * 128 + q * 8) * 2;
+        dvo[s] = dcb < a.d_cbytes ? (uint32_t)(row * a.d_pitch2 + dcb) : 0xffffffffu;
+        const int tl = q / a.gcb8, cc = q - tl * a.gcb8;
+        const int tap = tg * a.ntpt + tl;
+        const int gcbyte = (gb * 128 + cc * 8) * 2;
+        const bool ok = tl < a.ntpt && tap < a.T && gcbyte < a.g_cbytes;
+        gtap[s] = ok ? (uint32_t)tap : 64u;
+        gadd[s] = ok ? a.toff[tap & 63] + gcbyte : 0;
+    }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CL_WG_ISSUE(ST, BUF, E0, E1)                                                                                          \
+    {                                                                                                                         \
+        const int mrow_ = m_begin + (ST) * 32;                                                                                \
+        char* db_ = smem + (BUF) * STAGE;                                                                                     \
+        char* gb_ = db_ + IMG;                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                       \
+            const uint32_t dv_ = (mrow_ + rowi[s] < m_end) ? dvo[s] : 0xffffffffu;                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(db_ + (s * 256 + wave * 64) * 16), 16, dv_, mrow_ * a.d_pitch2, 0, 0); \
+            const ClPosEntry& e_ = s ? (E1) : (E0);                                                                           \
+            const bool ok_ = gtap[s] < 64u && ((e_.vmask >> gtap[s]) & 1ull) && (mrow_ + rowi[s] < m_end);                    \
+            const uint32_t gv_ = ok_ ? (uint32_t)(e_.gbase + gadd[s]) : 0xffffffffu;                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void_t*)(gb_ + (s * 256 + wave * 64) * 16), 16, gv_, 0, 0, 0); \
+        }                                                                                                                     \
+    }
+#else
+#define CL_WG_ISSUE(ST, BUF, E0, E1) { (void)drs; (void)grs; (void)dvo; (void)gadd; (void)gtap; (void)rowi; }
+#endif
+#define CL_WG_ENTRY(ST, S) a.tab[min(m_begin + (ST) * 32 + rowi[S], a.M - 1)]
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing fragment reads: lane group g = lane >> 4 (columns 16 (g & 1) .., k half g >> 1), lane (qq, p) of the group supplies the address of
+    // row 16 kk + 8 (g >> 1) + 4 s + qq, columns 4 p .. 4 p + 3 of its 16
+    uint32_t fa[2][2][2], fb[2][2][2];   // [tile][kk][s]
+    {
+        const int g4 = lane >> 4, idx = lane & 15, qq = idx >> 2, p = idx & 3;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row = kk * 16 + 8 * (g4 >> 1) + 4 * s + qq;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int cha = (wd * 64 + i * 32) / 8 + 2 * (g4 & 1) + (p >> 1);
+                    const int chb = (wj * 64 + i * 32) / 8 + 2 * (g4 & 1) + (p >> 1);
+                    fa[i][kk][s] = (uint32_t)(row * 256 + ((cha ^ cl_swz(row)) << 4) + 8 * (p & 1));
+                    fb[i][kk][s] = (uint32_t)(IMG + row * 256 + ((chb ^ cl_swz(row)) << 4) + 8 * (p & 1));
+                }
+            }
+    }
+
+    if (nst > 0) {
+        ClPosEntry e0 = CL_WG_ENTRY(0, 0), e1 = CL_WG_ENTRY(0, 1);
+        CL_WG_ISSUE(0, 0, e0, e1)
+        if (nst > 1) { e0 = CL_WG_ENTRY(1, 0); e1 = CL_WG_ENTRY(1, 1); }
+        for (int st = 0; st < nst; ++st) {
+            const int buf = st & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (st + 1 < nst) CL_WG_ISSUE(st + 1, buf ^ 1, e0, e1)
+            ClPosEntry n0 = e0, n1 = e1;
+            if (st + 2 < nst) { n0 = CL_WG_ENTRY(st + 2, 0); n1 = CL_WG_ENTRY(st + 2, 1); }
+            const char* sb = smem + buf * STAGE;
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fa[i][kk][0]));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fa[i][kk][1]));
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fb[i][kk][0]));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fb[i][kk][1]));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    af[i] = __builtin_bit_cast(bf16x8, av);
+                    bfr[i] = __builtin_bit_cast(bf16x8, bv);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            e0 = n0; e1 = n1;
+        }
+    }
+    float* __restrict__ out = a.slab + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dc = wd * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int vc = wj * 64 + j * 32 + l31;
+                out[dc * 128 + vc] = acc[i][j][r];
+            }
+}
+#undef CL_WG_ISSUE
+#undef CL_WG_ENTRY
+
+// dw[dc * ws_d + gc * T + t] = sum_s slab[s][tile(dc, t, gc)][dc % 128][vcol]   (fixed order)
+struct ClWgradReduceArgs {
+    const float* slab;
+    float* dw;
+    int32_t S, tiles, tiles_d, gblocks, gcb, ntpt, T, DC, GC;
+    int64_t ws_d;
+};
+__global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduceArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)a.DC * a.GC * a.T;
+    if (i >= tot) return;
+    const int t = (int)(i % a.T), gc = (int)((i / a.T) % a.GC), dc = (int)(i / ((int64_t)a.T * a.GC));
+    const int d_t = dc >> 7, tg = t / a.ntpt, tl = t - tg * a.ntpt, gbk = gc >> 7;
+    const int j_t = tg * a.gblocks + gbk;
+    const int tile = j_t * a.tiles_d + d_t;
+    const int vc = tl * a.gcb + (gc & 127);
+    const float* p = a.slab + ((int64_t)tile * 128 + (dc & 127)) * 128 + vc;
+    float s = 0.f;
+    for (int k = 0; k < a.S; ++k) s += p[(int64_t)k * a.tiles * (128 * 128)];
+    a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
+}
+
+struct ClTile { int bn, bm; };
+static ClTile cl_pick_tile(int OC) {
+    if (OC > 64) return {128, 128};
+    if (OC > 32) return {64, 256};
+    return {32, 256};
+}
+
+static size_t cl_class_pack_bytes(const ClClass& c, int C, int OC) {
+    const ClTile tc = cl_pick_tile(OC);
+    const int OCp = (OC + tc.bn - 1) / tc.bn * tc.bn;
+    const int T = c.t[0].n * c.t[1].n * c.t[2].n;
+    if (T == 0) return 0;
+    const int nsteps = cl_thin(C) ? (T + 3) / 4 : T * (cl_cp(C) / 32);
+    return align_up((size_t)nsteps * OCp * 64, 256);
+}
+
+// src (gathered, RC channels) -> dst (OC channels); weight element (oc, rc, tap) at oc * ws_o + rc * ws_r + kidx
+struct ClPlan {
+    std::vector<ClClass> cls;
+    int RC, OC;
+    int64_t ws_o, ws_r;
+    int KH, KW;
+};
+
+static int cl_make_plan(int which, const dcv_conv_geom* g, const dcv_dims5* xd, const dcv_dims5* yd, ClPlan* pl) {
+    const int k[3] = {g->kd, g->kh, g->kw}, s[3] = {g->sd, g->sh, g->sw}, p[3] = {g->pd, g->ph, g->pw};
+    const int xi[3] = {xd->d, xd->h, xd->w}, yo[3] = {yd->d, yd->h, yd->w};
+    const int T = k[0] * k[1] * k[2];
+    if (k[0] > 4 || k[1] > 4 || k[2] > 4) return fail(DCV_EUNSUPPORTED, "cl conv: filters up to 4 taps per dim");
+    for (int d = 0; d < 3; ++d) {
+        const int want = g->transposed ? (xi[d] - 1) * s[d] - 2 * p[d] + k[d] : (xi[d] + 2 * p[d] - k[d]) / s[d] + 1;
+        if (want != yo[d]) return fail(DCV_EINVAL, "cl conv: output extent %d along dim %d, geometry gives %d", yo[d], d, want);
+    }
+    if (xd->c != g->cin || yd->c != g->cout || xd->n != yd->n) return fail(DCV_EINVAL, "cl conv: channel / batch mismatch");
+    const bool direct = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
+    const dcv_dims5& src = (which == 0) ? *xd : *yd;
+    const dcv_dims5& dst = (which == 0) ? *yd : *xd;
+    pl->RC = src.c; pl->OC = dst.c; pl->KH = k[1]; pl->KW = k[2];
+    if (direct) {
+        pl->cls = cl_direct_classes(k, s, p, (which == 0) ? yo : xi, (which == 0) ? xi : yo);
+        pl->ws_o = (int64_t)pl->RC * T; pl->ws_r = T;
+    } else {
+        pl->cls = cl_scatter_classes(k, s, p, (which == 0) ? yo : xi, (which == 0) ? xi : yo);
+        pl->ws_o = T; pl->ws_r = (int64_t)pl->OC * T;
+    }
+    return DCV_OK;
+}
+
+static int cl_check_tensor(const dcv_dims5& d, const char* tag) {
+    if (d.c > 1 && d.sc != 1) return fail(DCV_EINVAL, "%s: channels-last tensor expected (channel stride 1, got %lld)", tag, (long long)d.sc);
+    if ((d.w > 1 && d.sw % 8) || (d.h > 1 && d.sh % 8) || (d.d > 1 && d.sd % 8) || (d.n > 1 && d.sn % 8)) return fail(DCV_EINVAL, "%s: pixel pitch must be a multiple of 8 elements", tag);
+    return DCV_OK;
+}
+// bytes from the tensor's first element to one past its last pixel's padded channels (all strides non-negative)
+static int64_t cl_extent_bytes(const dcv_dims5& d, int cpad) {
+    return 2 * ((int64_t)(d.n - 1) * d.sn + (int64_t)(d.d - 1) * d.sd + (int64_t)(d.h - 1) * d.sh + (int64_t)(d.w - 1) * d.sw + cpad);
+}
+
+template <int TOC, int TM, int WOC, int WM>
+static void cl_launch_gather(const ClGatherPack& pk, bool thin, dim3 grid, hipStream_t s) {
+    if (thin) hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, pk);
+    else hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, false>), grid, dim3(256), 0, s, pk);
+}
+
+
+static bool cl_pixel_linear(const dcv_dims5& d, int64_t* pitch) {
+    int64_t p = 0;
+    if (d.w > 1) p = d.sw; else if (d.h > 1) p = d.sh; else if (d.d > 1) p = d.sd; else if (d.n > 1) p = d.sn; else p = pad8(d.c);
+    if ((d.h > 1 && d.sh != (int64_t)d.w * p) || (d.d > 1 && d.sd != (int64_t)d.h * d.w * p) || (d.n > 1 && d.sn != (int64_t)d.d * d.h * d.w * p)) return false;
+    *pitch = p;
+    return true;
+}
+struct ClWgradPlan {
+    int64_t M;
+    int DC, GC, T, tiles_d, gblocks, gcb, ntpt, tiles_j, tiles, S, chunk;
+    size_t tab_bytes, slab_bytes;
+};
+static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_dims5& G, ClWgradPlan* p) {
+    p->M = (int64_t)D.n * D.d * D.h * D.w;
+    if (p->M >= (1ll << 31) || p->M == 0) return fail(DCV_EUNSUPPORTED, "cl wgrad: position count");
+    p->DC = D.c; p->GC = G.c; p->T = g->kd * g->kh * g->kw;
+    if (p->T > 64) return fail(DCV_EUNSUPPORTED, "cl wgrad: more than 64 taps");
+    const int gcp = pad8(G.c);
+    if (gcp >= 128) { p->gcb = 128; p->gblocks = (gcp + 127) / 128; p->ntpt = 1; }
+    else { p->gcb = gcp; p->gblocks = 1; p->ntpt = 128 / gcp; }
+    p->tiles_d = (pad8(D.c) + 127) / 128;
+    p->tiles_j = (p->T + p->ntpt - 1) / p->ntpt * p->gblocks;
+    p->tiles = p->tiles_d * p->tiles_j;
+    int64_t S = (1024 + p->tiles - 1) / p->tiles;
+    const int64_t maxS = std::max<int64_t>(1, p->M / 256);
+    S = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S, maxS), 256));
+    int64_t chunk = ((p->M + S - 1) / S + 31) / 32 * 32;
+    S = (p->M + chunk - 1) / chunk;
+    p->S = (int)S; p->chunk = (int)chunk;
+    p->tab_bytes = align_up((size_t)p->M * sizeof(ClPosEntry), 256);
+    p->slab_bytes = (size_t)S * p->tiles * 128 * 128 * sizeof(float);
+    return DCV_OK;
+}
+
+}  // namespace dcv
+
+using namespace dcv;
+
+extern "C" {
+
+size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
+    ClPlan pl;
+    if (!g || !x || !y || (which != 0 && which != 1) || cl_make_plan(which, g, x, y, &pl) != DCV_OK) return 0;
+    size_t tot = 0;
+    for (const ClClass& c : pl.cls) tot += cl_class_pack_bytes(c, pl.RC, pl.OC);
+    return tot + 256;
+}
+
+int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which, const float* w, void* packed, size_t bytes, void* stream) {
+    ClPlan pl;
+    if (!g || !x || !y || !w || !packed) return fail(DCV_EINVAL, "cl_pack_weights: null pointer");
+    int rc = cl_make_plan(which, g, x, y, &pl);
+    if (rc != DCV_OK) return rc;
+    const ClTile tc = cl_pick_tile(pl.OC);
+    ClPackArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    size_t off = 0;
+    int n = 0;
+    int64_t maxtot = 0;
+    pa.OC = pl.OC; pa.OCp = (pl.OC + tc.bn - 1) / tc.bn * tc.bn; pa.C = pl.RC; pa.cblk = cl_thin(pl.RC) ? 0 : cl_cp(pl.RC) / 32;
+    pa.ws_o = pl.ws_o; pa.ws_r = pl.ws_r;
+    for (const ClClass& c : pl.cls) {
+        const int T = c.t[0].n * c.t[1].n * c.t[2].n;
+        const size_t b = cl_class_pack_bytes(c, pl.RC, pl.OC);
+        if (T == 0) continue;
+        if (off + b > bytes) return fail(DCV_EWORKSPACE, "cl_pack_weights: buffer too small");
+        pa.wp[n] = reinterpret_cast<__bf16*>(static_cast<char*>(packed) + off);
+        pa.T[n] = T;
+        pa.nsteps[n] = cl_thin(pl.RC) ? (T + 3) / 4 : T * (cl_cp(pl.RC) / 32);
+        for (int t = 0; t < T; ++t) {
+            const int ud = t / (c.t[1].n * c.t[2].n), uh = (t / c.t[2].n) % c.t[1].n, uw = t % c.t[2].n;
+            pa.kidx[n][t] = (c.t[0].kidx[ud] * pl.KH + c.t[1].kidx[uh]) * pl.KW + c.t[2].kidx[uw];
+        }
+        maxtot = std::max<int64_t>(maxtot, (int64_t)pa.nsteps[n] * pa.OCp * 32);
+        off += b;
+        if (++n > 4) return fail(DCV_EUNSUPPORTED, "cl_pack_weights: more than 4 position classes");
+    }
+    if (n == 0) return DCV_OK;
+    pa.ncls = n;
+    hipLaunchKernelGGL(cl_pack_kernel, dim3((unsigned)((maxtot + 255) / 256), (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), w, pa);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+// which: 0 forward (x -> y), 1 backward-data (dy -> dx); src / dst are bf16 channels-last
+static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, const dcv_dims5* xd, const void* packed, void* dst_p, const dcv_dims5* yd,
+                       int act, float slope, int accumulate, void* stream) {
+    if (!g || !xd || !yd || !src_p || !packed || !dst_p) return fail(DCV_EINVAL, "cl conv: null pointer");
+    ClPlan pl;
+    int rc = cl_make_plan(which, g, xd, yd, &pl);
+    if (rc != DCV_OK) return rc;
+    const dcv_dims5& src = (which == 0) ? *xd : *yd;
+    const dcv_dims5& dst = (which == 0) ? *yd : *xd;
+    if ((rc = cl_check_tensor(src, "cl conv source")) != DCV_OK || (rc = cl_check_tensor(dst, "cl conv destination")) != DCV_OK) return rc;
+    const bool thin = cl_thin(pl.RC);
+    const int Cp = cl_cp(pl.RC);
+    // the gathered tensor's channel slice must be readable in whole K granules: pixel pitch >= padded channel count
+    if (src.w > 1 && src.sw < (thin ? 8 : Cp)) return fail(DCV_EINVAL, "cl conv: source pixel pitch %lld < padded channels %d", (long long)src.sw, thin ? 8 : Cp);
+    const int ocs = (pl.OC + 3) / 4 * 4;      // stores are 4-channel groups: the destination's pixel pitch must have room for them
+    if (dst.w > 1 && dst.sw < ocs) return fail(DCV_EINVAL, "cl conv: destination pixel pitch %lld < %d stored channels", (long long)dst.sw, ocs);
+    const ClTile tc = cl_pick_tile(pl.OC);
+    const int OCp = (pl.OC + tc.bn - 1) / tc.bn * tc.bn;
+    const int64_t xb = cl_extent_bytes(src, thin ? 8 : Cp), yb = cl_extent_bytes(dst, ocs);
+    if (xb >= (1ll << 31) || yb >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: tensors beyond 2 GB need per-sample descriptors");
+    ClGatherPack pk;
+    memset(&pk, 0, sizeof(pk));
+    size_t off = 0;
+    int n = 0;
+    int64_t maxtm = 0;
+    for (const ClClass& c : pl.cls) {
+        const int T = c.t[0].n * c.t[1].n * c.t[2].n;
+        const size_t b = cl_class_pack_bytes(c, pl.RC, pl.OC);
+        if (T == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) {
+            if (T != 0) off += b;
+            if (T == 0 && c.o_ext[0] > 0 && c.o_ext[1] > 0 && c.o_ext[2] > 0 && !accumulate) return fail(DCV_EUNSUPPORTED, "cl conv: a position class without taps");
+            continue;
+        }
+        if (T > 64) return fail(DCV_EUNSUPPORTED, "cl conv: more than 64 taps");
+        ClGatherArgs& a = pk.c[n];
+        a.x = static_cast<const __bf16*>(src_p);
+        a.y = static_cast<__bf16*>(dst_p);
+        a.wp = reinterpret_cast<const __bf16*>(static_cast<const char*>(packed) + off);
+        off += b;
+        const int64_t M64 = (int64_t)dst.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+        if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: too many positions");
+        a.M = (int)M64; a.OCp = OCp; a.T = T;
+        a.cblk = thin ? 0 : Cp / 32;
+        a.nsteps = thin ? (T + 3) / 4 : T * (Cp / 32);
+        a.y_c = ocs;
+        a.x_cmax = 2 * (thin ? 8 : Cp);
+        a.div_sp = make_fastdiv((uint32_t)(c.o_ext[0] * c.o_ext[1] * c.o_ext[2]));
+        a.div_hw = make_fastdiv((uint32_t)(c.o_ext[1] * c.o_ext[2]));
+        a.div_w = make_fastdiv((uint32_t)c.o_ext[2]);
+        a.td = c.t[0]; a.th = c.t[1]; a.tw = c.t[2];
+        a.x_sn = src.sn; a.x_sd = (int32_t)src.sd; a.x_sh = (int32_t)src.sh; a.x_sw = (int32_t)src.sw;
+        a.y_sn = dst.sn;
+        a.y_sd = (int32_t)(dst.sd * c.out_mul[0]); a.y_sh = (int32_t)(dst.sh * c.out_mul[1]); a.y_sw = (int32_t)(dst.sw * c.out_mul[2]);
+        a.y_off = (int32_t)(dst.sd * c.out_off[0] + dst.sh * c.out_off[1] + dst.sw * c.out_off[2]);
+        a.act = act; a.slope = slope; a.accumulate = accumulate;
+        a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
+        for (int t = 0; t < T; ++t) {
+            const int ud = t / (c.t[1].n * c.t[2].n), uh = (t / c.t[2].n) % c.t[1].n, uw = t % c.t[2].n;
+            a.toff[t] = (int32_t)(2 * ((int64_t)c.t[0].delta[ud] * src.sd + (int64_t)c.t[1].delta[uh] * src.sh + (int64_t)c.t[2].delta[uw] * src.sw));
+            a.tsel[t] = ud | (uh << 2) | (uw << 4);
+        }
+        maxtm = std::max<int64_t>(maxtm, (M64 + tc.bm - 1) / tc.bm);
+        if (++n > 4) return fail(DCV_EUNSUPPORTED, "cl conv: more than 4 position classes");
+    }
+    if (n == 0) return DCV_OK;
+    for (int i = n; i < 4; ++i) pk.c[i] = pk.c[0];
+    pk.ncls = n; pk.tiles_oc = OCp / tc.bn; pk.tiles_m = (int)maxtm;
+    const dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (tc.bn == 128) cl_launch_gather<2, 2, 2, 2>(pk, thin, grid, st);
+    else if (tc.bn == 64) cl_launch_gather<2, 2, 1, 4>(pk, thin, grid, st);
+    else cl_launch_gather<1, 2, 1, 4>(pk, thin, grid, st);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile%s> (%d class%s, bf16 channels-last)", tc.bn, tc.bm, thin ? ", thin" : "", n, n == 1 ? "" : "es");
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_cl_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
+                        int act, float slope, void* stream) {
+    return cl_conv_run(0, g, x, xd, packed, y, yd, act, slope, 0, stream);
+}
+int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
+                              int accumulate, void* stream) {
+    return cl_conv_run(1, g, dy, dxd, packed, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, stream);
+}
+
+size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y) {
+    if (!g || !x || !y) return 0;
+    ClWgradPlan p;
+    if (cl_wgrad_plan(g, g->transposed ? *x : *y, g->transposed ? *y : *x, &p) != DCV_OK) return 0;
+    return p.tab_bytes + p.slab_bytes + 512;
+}
+
+// dw (fp32, torch layout) = corr(x, dy); x and dy bf16 channels-last.  conv: dense = dy, gathered = x; transposed conv: dense = x, gathered = dy.
+int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
+                                void* ws, size_t ws_bytes, void* stream) {
+    if (!g || !x || !xd || !dy || !dyd || !dw || !ws) return fail(DCV_EINVAL, "cl_conv_backward_weight: null pointer");
+    ClPlan chk;
+    int rc = cl_make_plan(0, g, xd, dyd, &chk);      // validates the geometry
+    if (rc != DCV_OK) return rc;
+    const dcv_dims5& D = g->transposed ? *xd : *dyd;
+    const dcv_dims5& G = g->transposed ? *dyd : *xd;
+    const __bf16* dp = static_cast<const __bf16*>(g->transposed ? x : dy);
+    const __bf16* gp = static_cast<const __bf16*>(g->transposed ? dy : x);
+    if ((rc = cl_check_tensor(D, "cl wgrad dense operand")) != DCV_OK || (rc = cl_check_tensor(G, "cl wgrad gathered operand")) != DCV_OK) return rc;
+    int64_t dpitch = 0;
+    if (!cl_pixel_linear(D, &dpitch)) return fail(DCV_EUNSUPPORTED, "cl wgrad: the dense operand must be pixel-linear (a whole tensor or a channel slice of one)");
+    ClWgradPlan p;
+    if ((rc = cl_wgrad_plan(g, D, G, &p)) != DCV_OK) return rc;
+    if (ws_bytes < p.tab_bytes + p.slab_bytes) return fail(DCV_EWORKSPACE, "cl wgrad: workspace too small (%zu needed, %zu given)", p.tab_bytes + p.slab_bytes, ws_bytes);
+    const int64_t dbytes = 2 * ((p.M - 1) * dpitch + pad8(D.c)), gbytes = cl_extent_bytes(G, pad8(G.c));
+    if (dbytes >= (1ll << 31) || gbytes >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl wgrad: tensors beyond 2 GB");
+    if (G.w > 1 && G.sw < pad8(G.c)) return fail(DCV_EINVAL, "cl wgrad: gathered operand's pixel pitch below its padded channel count");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ClPosEntry* tab = static_cast<ClPosEntry*>(ws);
+    float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + p.tab_bytes);
+    {
+        ClPosArgs a;
+        memset(&a, 0, sizeof(a));
+        a.tab = tab; a.M = (int)p.M; a.T = p.T; a.KH = g->kh; a.KW = g->kw;
+        a.div_sp = make_fastdiv((uint32_t)(D.d * D.h * D.w)); a.div_hw = make_fastdiv((uint32_t)(D.h * D.w)); a.div_w = make_fastdiv((uint32_t)D.w);
+        a.s[0] = g->sd; a.s[1] = g->sh; a.s[2] = g->sw; a.p[0] = g->pd; a.p[1] = g->ph; a.p[2] = g->pw; a.k[0] = g->kd; a.k[1] = g->kh; a.k[2] = g->kw;
+        a.gext[0] = G.d; a.gext[1] = G.h; a.gext[2] = G.w;
+        a.g_sn = G.sn; a.g_sd = (int32_t)G.sd; a.g_sh = (int32_t)G.sh; a.g_sw = (int32_t)G.sw;
+        hipLaunchKernelGGL(cl_postab_kernel, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, a);
+        DCV_LAUNCH_CHECK();
+    }
+    {
+        ClWgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.d = dp; a.g = gp; a.tab = tab; a.slab = slab;
+        a.M = (int)p.M; a.chunk = p.chunk;
+        a.d_pitch2 = (int32_t)(2 * dpitch); a.d_cbytes = 2 * pad8(D.c); a.g_cbytes = 2 * pad8(G.c); a.T = p.T;
+        a.tiles_d = p.tiles_d; a.gblocks = p.gblocks; a.gcb8 = p.gcb / 8; a.ntpt = p.ntpt;
+        a.d_bytes = (uint32_t)dbytes; a.g_bytes = (uint32_t)gbytes;
+        for (int t = 0; t < p.T; ++t) {
+            const int kd = t / (g->kh * g->kw), kh = (t / g->kw) % g->kh, kw = t % g->kw;
+            a.toff[t] = (int32_t)(2 * ((int64_t)kd * G.sd + (int64_t)kh * G.sh + (int64_t)kw * G.sw));
+        }
+        hipLaunchKernelGGL(cl_wgrad_kernel, dim3((unsigned)p.tiles, (unsigned)p.S), dim3(256), 0, st, a);
+        DCV_LAUNCH_CHECK();
+    }
+    {
+        ClWgradReduceArgs a;
+        memset(&a, 0, sizeof(a));
+        a.slab = slab; a.dw = dw; a.S = p.S; a.tiles = p.tiles; a.tiles_d = p.tiles_d; a.gblocks = p.gblocks; a.gcb = p.gcb; a.ntpt = p.ntpt; a.T = p.T;
+        a.DC = D.c; a.GC = G.c; a.ws_d = (int64_t)G.c * p.T;
+        const int64_t tot = (int64_t)D.c * G.c * p.T;
+        hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a);
+        DCV_LAUNCH_CHECK();
+    }
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, bf16 channels-last)", p.tiles, p.S);
+    return DCV_OK;
+}
+
+}  // extern "C"

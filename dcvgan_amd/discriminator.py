@@ -13,7 +13,7 @@ import json
 import torch
 import torch.nn as nn
 
-from . import layers, ops, util
+from . import layers, ops, ops_cl, util
 from .rng import default_rng
 
 _S3, _P3 = (1, 2, 2), (0, 1, 1)
@@ -63,6 +63,11 @@ class _PairDiscriminator(nn.Module):
         conv = self.conv_g[-2]
         half = conv.out_channels
         sp = ops._out_shape(layers.geom_of(conv), xg)[2:]
+        if ops_cl.active():   # bf16 channels-last data path inside the module; fp32 (strided views included) at its boundary
+            cat = ops_cl.ConcatBuffer(xg.shape[0], half, half, sp, xg.device)
+            hg = layers.run(self.conv_g, ops_cl.from_f32(xg), rng, out=cat.second)
+            hc = layers.run(self.conv_c, ops_cl.from_f32(xc), rng, out=cat.first)
+            return ops_cl.to_f32(layers.run(self.main, cat.join(hc, hg), rng)).squeeze()
         cat = ops.ConcatBuffer(xg.shape[0], half, half, sp, xg.device)
         hg = layers.run(self.conv_g, xg, rng, out=cat.second)   # draw order: geometry stem first (discriminator.py:122-123)
         hc = layers.run(self.conv_c, xc, rng, out=cat.first)
@@ -119,6 +124,8 @@ class GradientDiscriminator(_PairDiscriminator):
         self.device = util.current_device()
 
     def forward(self, xg, xc):
+        if ops_cl.active():
+            return ops_cl.to_f32(layers.run(self.main, ops_cl.from_f32(ops.temporal_diff(xg)), self._source())).squeeze()
         return layers.run(self.main, ops.temporal_diff(xg), self._source()).squeeze()
 
     def __str__(self, name: str = "vdis") -> str:  # the reference labels it "vdis" too (discriminator.py:335)

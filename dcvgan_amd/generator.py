@@ -14,7 +14,7 @@ import json
 import torch
 import torch.nn as nn
 
-from . import layers, ops, util
+from . import layers, ops, ops_cl, util
 from .rng import default_rng
 
 
@@ -75,7 +75,10 @@ class GeometricVideoGenerator(nn.Module):
 
     def sample_videos(self, batchsize: int) -> torch.Tensor:
         z = self.sample_z_video(batchsize)
-        frames = layers.run(self.main, z.view(-1, self.dim_z, 1, 1), self._source())
+        if ops_cl.active():   # bf16 channels-last data path inside the module; fp32 at its boundary (latents in, frames out)
+            frames = ops_cl.to_f32(layers.run(self.main, ops_cl.from_f32(z.view(-1, self.dim_z, 1, 1)), self._source()))
+        else:
+            frames = layers.run(self.main, z.view(-1, self.dim_z, 1, 1), self._source())
         return frames.view(batchsize, self.video_length, self.channel, 64, 64).permute(0, 2, 1, 3, 4)
 
     def __str__(self, name: str = "ggen") -> str:
@@ -160,6 +163,8 @@ class ColorVideoGenerator(nn.Module):
         rng = self._source()
         if self.geometric_info == "segmentation":  # one-hot -> {-1, +1} maps (generator.py:378-385); SURVEY §8(f).4
             x = ops.segm_onehot(x)
+        if ops_cl.active():
+            return self._forward_cl(x, z, rng)
         # Every torch.cat of the reference (generator.py:393-400) joins an up-path tensor with a skip:
         # both producers write straight into the two channel slices of one buffer, so no copy is made.
         nb = x.shape[0]
@@ -179,6 +184,26 @@ class ColorVideoGenerator(nn.Module):
             h = blk(h, rng, out=bufs[5 - i].first)
             h = bufs[5 - i].join(h, skips[5 - i])
         return self.outconv(h, rng)
+
+    def _forward_cl(self, x, z, rng):
+        """The same U-Net on the bf16 channels-last data path: x, z fp32 in, RGB frames fp32 out; every concatenation is two channel ranges of
+        one channels-last buffer (whose pixel pitch is rounded up to whole 32-channel K blocks: the 256 + dim_z bottleneck gets zero padding)."""
+        nb = x.shape[0]
+        widths = [self.inconv.main[0].out_channels] + [b.main[0].out_channels for b in self.down_blocks]
+        ups = [b.main[0].out_channels for b in self.up_blocks]
+        size = [x.shape[2] >> k for k in range(7)]
+        bufs = [ops_cl.ConcatBuffer(nb, ups[5 - k], widths[k], (size[k], size[k]), x.device) for k in range(6)]
+        bufs.append(ops_cl.ConcatBuffer(nb, widths[6], self.dim_z, (size[6], size[6]), x.device))
+        skips = [self.inconv(ops_cl.from_f32(x), rng, out=bufs[0].second)]
+        for k, blk in enumerate(self.down_blocks):
+            dst = bufs[k + 1].second if k + 1 < 6 else bufs[6].first
+            skips.append(blk(skips[-1], rng, out=dst))
+        zc = ops_cl.from_f32(z, out=bufs[6].second)
+        h = bufs[6].join(skips[6], zc)
+        for i, blk in enumerate(self.up_blocks):
+            h = blk(h, rng, out=bufs[5 - i].first)
+            h = bufs[5 - i].join(h, skips[5 - i])
+        return ops_cl.to_f32(self.outconv(h, rng))
 
     def forward_videos(self, xs: torch.Tensor) -> torch.Tensor:
         B, Cg, T, H, W = xs.shape

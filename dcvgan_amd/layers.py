@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, ops_cl
 
 import os
 
@@ -60,6 +60,9 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, part
     mask = None
     if dropout is not None and dropout.training:
         mask = rng.dropout2d_mask(x.shape[0], x.shape[1], dropout.p, x.device)
+    if ops_cl.is_cl(x):     # bf16 channels-last data path (ops_cl): statistics from its own pass over the bf16 tensor
+        return ops_cl.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
+                             bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, num_batches_tracked=bn.num_batches_tracked if training else None)
     # num_batches_tracked is bumped by the statistics kernel itself (one launch less per BatchNorm layer)
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
                       bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, partials=partials if training else None,
@@ -77,7 +80,13 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
     while i < n:
         layer = layers[i]
         nxt = layers[i + 1] if i + 1 < n else None
-        if isinstance(layer, _CONVS):
+        if isinstance(layer, _CONVS) and ops_cl.is_cl(x):
+            # bf16 channels-last data path: the same grouping (conv [+ activation] in one launch), ops_cl's kernels
+            fused = _act_of(nxt) if nxt is not None else None
+            last = i + (2 if fused is not None else 1) >= n
+            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None)
+            i += 2 if fused is not None else 1
+        elif isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None
             if fused is not None:
                 x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None, grad_slot=grad_slot if i == 0 else None,
@@ -104,7 +113,7 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             i = j
         elif _act_of(layer) is not None:
             code, slope = _act_of(layer)
-            x = ops.act(x, code, slope)
+            x = ops_cl.act(x, code, slope) if ops_cl.is_cl(x) else ops.act(x, code, slope)
             _tap(x, (code, slope))
             i += 1
         elif hasattr(layer, "use_noise") and hasattr(layer, "sigma"):  # discriminator.Noise
@@ -114,6 +123,8 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
         elif isinstance(layer, nn.Softmax):  # segmentation head (generator.py:75-76)
             if layer.dim != 1:
                 raise NotImplementedError("only the channel softmax of the segmentation head is implemented")
+            if ops_cl.is_cl(x):
+                raise NotImplementedError("the segmentation head is not part of the bf16 channels-last path (no BASELINE config uses it there)")
             x = ops.softmax_channels(x)
             i += 1
         else:

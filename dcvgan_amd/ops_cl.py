@@ -1,0 +1,303 @@
+"""Autograd tape entries of the bf16 channels-last ("CL16") data path (csrc/conv_cl16.hip, csrc/cl_elementwise.hip).
+
+BASELINE.json configs[2] / [4] name 16-bit MFMA variants of the step; the reference itself is fp32-only, so this is a throughput path
+with its own tolerance, never the default and never what a parity claim refers to.  Inside a model activations and their gradients
+are bf16 tensors whose memory order is (n, d, h, w, c) — torch sees them as ordinary (N, C, [D,] H, W) tensors with permuted strides,
+channel stride 1 and a pixel pitch of `pitch_of(C)` elements, padding channels zero — while parameters, BatchNorm statistics, weight
+gradients and the optimiser stay fp32 and the module boundary (generator outputs, discriminator inputs and logits) stays fp32 NCDHW.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import native as N
+from .native import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvGeom, check, dims5, lib, ptr, stream_ptr
+from .ops import _Opaque, _Out, _out_shape, _ws
+
+BF16 = torch.bfloat16
+_ENABLED = [False]
+
+
+def enable(on: bool = True) -> None:
+    """Process-wide switch: models built on dcvgan_amd.layers run their convolution / BatchNorm chains on the CL16 path."""
+    _ENABLED[0] = bool(on)
+
+
+def active() -> bool:
+    return _ENABLED[0]
+
+
+def pitch_of(c: int) -> int:
+    """Pixel pitch (elements) of a CL16 tensor with c channels: 8 for thin tensors (<= 8 channels: one 16-byte K granule per tap), else whole
+    32-channel K blocks — what the gather kernel reads per (pixel, tap)."""
+    return 8 if c <= 8 else (c + 31) // 32 * 32
+
+
+def cl_empty(shape, device, pitch: Optional[int] = None) -> torch.Tensor:
+    """(N, C, [D,] H, W) bf16 tensor in channels-last memory; padding channels (C < pitch) are zero."""
+    n, c, sp = shape[0], shape[1], tuple(shape[2:])
+    p = pitch if pitch is not None else pitch_of(c)
+    make = torch.zeros if p != c else torch.empty
+    store = make((n,) + sp + (p,), dtype=BF16, device=device)
+    perm = (0, len(sp) + 1) + tuple(range(1, len(sp) + 1))
+    return store.permute(*perm)[:, :c]
+
+
+def is_cl(t: torch.Tensor) -> bool:
+    return t.dtype == BF16
+
+
+def _req(t: torch.Tensor, what: str):
+    if not t.is_cuda or t.dtype != BF16:
+        raise N.NativeError(f"{what}: expected a bf16 HIP tensor, got {t.dtype} on {t.device}")
+    if t.dim() > 1 and t.shape[1] > 1 and t.stride(1) != 1:
+        raise N.NativeError(f"{what}: expected channels-last memory (channel stride 1), got strides {tuple(t.stride())}")
+    if t.device.index != torch.cuda.current_device():
+        raise N.NativeError(f"{what}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}")
+
+
+def as_cl(t: torch.Tensor) -> torch.Tensor:
+    """A gradient handed over by autograd: already channels-last in practice (sums of CL tensors keep their strides); anything else is re-laid."""
+    if t.dtype == BF16 and (t.shape[1] == 1 or t.stride(1) == 1) and all(s != 0 or n == 1 for s, n in zip(t.stride(), t.shape)):
+        st = t.stride()
+        if t.dim() < 3 or st[-1] % 8 == 0:
+            return t
+    out = cl_empty(t.shape, t.device)
+    out.copy_(t)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# module boundary
+# --------------------------------------------------------------------------- #
+class _FromF32(Function):
+    @staticmethod
+    def forward(ctx, x, out=None):
+        N._require(x, "from_f32 input")
+        y = cl_empty(x.shape, x.device) if out is None else out.t.detach()
+        xd, yd = dims5(x), dims5(y)
+        check(lib().dcv_cl_from_f32(ptr(x), C.byref(xd), ptr(y), C.byref(yd), stream_ptr()), "dcv_cl_from_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = as_cl(dy)
+        dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        dyd, dxd = dims5(dy), dims5(dx)
+        check(lib().dcv_cl_to_f32(ptr(dy), C.byref(dyd), ptr(dx), C.byref(dxd), 0, stream_ptr()), "dcv_cl_to_f32")
+        return dx, None
+
+
+def from_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 (any strides) -> CL16; `out`: destination view (a channel slice of a concat buffer)."""
+    return _FromF32.apply(x, None if out is None else _Out(out))
+
+
+class _ToF32(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req(x, "to_f32 input")
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        xd, yd = dims5(x), dims5(y)
+        check(lib().dcv_cl_to_f32(ptr(x), C.byref(xd), ptr(y), C.byref(yd), 0, stream_ptr()), "dcv_cl_to_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if any(s == 0 and n > 1 for s, n in zip(dy.stride(), dy.shape)):
+            dy = dy.contiguous()
+        dx = cl_empty(dy.shape, dy.device)
+        dyd, dxd = dims5(dy), dims5(dx)
+        check(lib().dcv_cl_from_f32(ptr(dy), C.byref(dyd), ptr(dx), C.byref(dxd), stream_ptr()), "dcv_cl_from_f32")
+        return dx
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    """CL16 -> contiguous fp32 NCDHW."""
+    return _ToF32.apply(x)
+
+
+# --------------------------------------------------------------------------- #
+# elementwise
+# --------------------------------------------------------------------------- #
+def _ew(kind, x, z, a=0.0, b=0.0, seed=0, offset=0, out=None):
+    y = cl_empty(x.shape, x.device, pitch=None) if out is None else out
+    xd, yd = dims5(x), dims5(y)
+    zd = dims5(z) if z is not None else None
+    check(lib().dcv_cl_elementwise(kind, ptr(x), C.byref(xd), ptr(z), C.byref(zd) if z is not None else None, ptr(y), C.byref(yd), float(a), float(b),
+                                   int(seed), int(offset), stream_ptr()), "dcv_cl_elementwise")
+    return y
+
+
+class _NoiseAddCl(Function):
+    @staticmethod
+    def forward(ctx, x, sigma, sample, seed, offset):
+        _req(x, "noise input")
+        if sample is not None:
+            return _ew(1, x, sample, 1.0, sigma)
+        return _ew(2, x, None, sigma, 0.0, seed, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None, None
+
+
+def noise_add(x, sigma: float, sample=None, seed: int = 0, offset: int = 0):
+    """x + sigma N(0,1) on a CL16 tensor; `sample`: an injected fp32 draw (converted) instead of the device Philox stream."""
+    if sample is not None and sample.dtype != BF16:
+        with torch.no_grad():
+            sample = from_f32(sample)
+    return _NoiseAddCl.apply(x, float(sigma), sample, int(seed), int(offset))
+
+
+class _ActCl(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _req(x, "activation input")
+        y = _ew(5 if act == ACT_LEAKY else 6, x, None, slope)
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        return _ew(3 if act == ACT_LEAKY else 4, as_cl(dy), y, slope), None, None
+
+
+def act(x, kind: int, slope: float = 0.0):
+    return _ActCl.apply(x, kind, float(slope))
+
+
+# --------------------------------------------------------------------------- #
+# convolution
+# --------------------------------------------------------------------------- #
+def _packed(w: torch.Tensor, which: int, g: ConvGeom, xd, yd, key_dims):
+    """bf16 K-major tiles of `w` for (pass, geometry): repacked when the tensor's autograd version (bumped by every optimiser step) changes."""
+    cache = getattr(w, "_dcv_clpack", None)
+    if cache is None:
+        cache = w._dcv_clpack = {}
+    key = (which, g.key(), key_dims)
+    e = cache.get(key)
+    stamp = (w._version, w.data_ptr())
+    L = lib()
+    if e is None:
+        nb = L.dcv_cl_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), which)
+        if nb == 0:
+            raise N.NativeError("dcv_cl_packed_bytes: " + L.dcv_last_error().decode())
+        e = cache[key] = [None, torch.empty(nb, dtype=torch.uint8, device=w.device)]
+    if e[0] != stamp:
+        check(L.dcv_cl_pack_weights(C.byref(g), C.byref(xd), C.byref(yd), which, ptr(w), ptr(e[1]), e[1].numel(), stream_ptr()), "dcv_cl_pack_weights")
+        e[0] = stamp
+    return e[1]
+
+
+class _ConvCl(Function):
+    @staticmethod
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None):
+        _req(x, "conv input"); N._require(w, "conv weight")
+        if x.shape[1] != g.cin:
+            raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
+        shape = _out_shape(g, x)
+        y = cl_empty(shape, x.device) if out is None else out.t.detach()
+        if tuple(y.shape) != tuple(shape):
+            raise N.NativeError(f"out= has shape {tuple(y.shape)}, expected {tuple(shape)}")
+        xd, yd = dims5(x), dims5(y)
+        pk = _packed(w, 0, g, xd, yd, tuple(x.shape))
+        check(lib().dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, stream_ptr()), "dcv_cl_conv_forward")
+        ctx.g, ctx.act, ctx.slope = g, act, slope
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        g = ctx.g
+        L = lib()
+        dy = as_cl(dy)
+        if ctx.act != ACT_NONE:
+            dy = _ew(3 if ctx.act == ACT_LEAKY else 4, dy, y, ctx.slope)
+        xd, dyd = dims5(x), dims5(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = cl_empty(x.shape, x.device)
+            dxd = dims5(dx)
+            pk = _packed(w, 1, g, dxd, dyd, tuple(x.shape))
+            check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 0, stream_ptr()), "dcv_cl_conv_backward_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            need = L.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd))
+            if need == 0:
+                raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + L.dcv_last_error().decode())
+            wsp, wsn = _ws("clconv", need, x.device)
+            check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
+        return dx, dw, None, None, None, None
+
+
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None):
+    """y = act(conv(x, w)) on CL16 tensors; fp32 weights in torch layout; `out`: destination view (a channel slice of a concat buffer)."""
+    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out))
+
+
+# --------------------------------------------------------------------------- #
+# BatchNorm (+ Dropout2d mask) + activation
+# --------------------------------------------------------------------------- #
+class _BnActCl(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training, momentum, eps, act, slope, out=None, nbt=None):
+        _req(x, "bn input")
+        L = lib()
+        Cn = x.shape[1]
+        y = cl_empty(x.shape, x.device) if out is None else out.t.detach()
+        stats = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        xd, yd = dims5(x), dims5(y)
+        wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
+        check(L.dcv_cl_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                      ptr(nbt) if training else None, ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope,
+                                      wsp, wsn, stream_ptr()), "dcv_cl_bn_act_forward")
+        ctx.cfg = (bool(training), act, slope)
+        ctx.save_for_backward(x, gamma, beta, stats, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats, mask = ctx.saved_tensors
+        training, act, slope = ctx.cfg
+        L = lib()
+        dy = as_cl(dy)
+        Cn = x.shape[1]
+        dx = cl_empty(x.shape, x.device)
+        dgb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
+        dyd, xd, dxd = dims5(dy), dims5(x), dims5(dx)
+        wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
+        check(L.dcv_cl_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]),
+                                       ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()), "dcv_cl_bn_act_backward")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0, mask=None, momentum: float = 0.1,
+           eps: float = 1e-5, out=None, num_batches_tracked=None):
+    return _BnActCl.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope),
+                          None if out is None else _Out(out), num_batches_tracked)
+
+
+# --------------------------------------------------------------------------- #
+# concatenation: both producers write into the two channel slices of one buffer
+# --------------------------------------------------------------------------- #
+class ConcatBuffer:
+    def __init__(self, n, ca, cb, spatial, device):
+        from .ops import _JoinSlices
+        self._join = _JoinSlices
+        if ca % 8:
+            raise N.NativeError("ConcatBuffer: the first member's channel count must be a multiple of 8 (16-byte aligned second slice)")
+        self.buf = cl_empty((n, ca + cb) + tuple(spatial), device)
+        self.first, self.second = self.buf[:, :ca], self.buf[:, ca:]
+        self.slot = None
+
+    def join(self, a, b):
+        return self._join.apply(a, b, _Out(self.buf), None)

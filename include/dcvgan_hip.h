@@ -255,6 +255,42 @@ int dcv_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
 int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* numel,
                         double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
+/* ---- bf16 channels-last ("CL16") data path -------------------------------------------------- *
+ * BASELINE.json configs[2] ("surreal-depth1, bf16 MFMA") and configs[4] ("fp16 MFMA") name 16-bit variants of the same step
+ * (config/surreal-depth1.yml:5,47-76, config/isogd-flow.yml; the reference itself is fp32-only).  This is that path as a DATA path:
+ * activations and their gradients are bf16 in HBM with the channel innermost (memory order n, d, h, w, c: `sc` = 1, the pixel pitch
+ * a multiple of 8 elements and >= the channel count rounded up to 8 — padding channels hold zeros), so an MFMA operand fragment
+ * (8 consecutive k = channels of one tap) is one 16-byte read for every stride / padding; weights stay fp32 masters in torch layout
+ * (packed to bf16 K-major tiles by dcv_cl_pack_weights, once per optimiser step), accumulators, BatchNorm statistics, weight gradients and
+ * the optimiser stay fp32.  v_mfma_f32_32x32x16_bf16.  Same call sites as the fp32 entry points above; `void*` tensors are bf16,
+ * described by dcv_dims5 with element strides.  A throughput path with its own tolerance (tests/test_cl16_gpu.py), never the default. */
+size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which /*0 fwd, 1 bwd-data*/);
+int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which, const float* w, void* packed, size_t bytes, void* stream);
+int dcv_cl_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
+                        int act, float slope, void* stream);
+int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
+                              int accumulate, void* stream);
+size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
+int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
+                                void* ws, size_t ws_bytes, void* stream);
+/* module boundary: fp32 NCDHW (any strides) <-> bf16 channels-last (same shape; padding channels are written as zeros).
+ * dcv_cl_to_f32 with accumulate = 1 adds into y (a gradient arriving at an fp32 leaf). */
+int dcv_cl_from_f32(const float* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, void* stream);
+int dcv_cl_to_f32(const void* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, int accumulate, void* stream);
+/* kind 0: y = x   1: y = a x + b z   2: y = x + a N(0,1) (Philox; discriminator.py:30-39)   3: dx = x * lrelu'(z; slope a) (x = dy, z = the activation's output)
+ * 4: dx = x * (1 - z^2) (tanh, z = output)   5: y = lrelu(x; a)   6: y = tanh(x) */
+int dcv_cl_elementwise(int kind, const void* x, const dcv_dims5* xd, const void* z, const dcv_dims5* zd, void* y, const dcv_dims5* yd,
+                       float a, float b, uint64_t seed, uint64_t offset, void* stream);
+/* BatchNorm{2,3}d (+ Dropout2d mask) (+ (Leaky)ReLU) on bf16 channels-last tensors; statistics, parameters and their gradients fp32
+ * (generator.py:62-72,205-211,242-248; discriminator.py:96-100,191-202,290-302).  Same semantics as dcv_bn_act_forward / _backward. */
+size_t dcv_cl_bn_workspace_bytes(int channels);
+int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                          const float* mask, int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, const dcv_dims5* xd, void* dx, const dcv_dims5* dxd,
+                           const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const float* mask,
+                           int training, int act, float slope, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

