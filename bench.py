@@ -53,10 +53,12 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing the DP path on one GPU)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6", "bf16cl"],
                     help="bf16: MFMA products in bf16 with fp32 accumulation in the large GEMM kernels (tensors, weights, statistics and "
                          "optimiser state stay fp32) — a secondary throughput line for BASELINE configs[2]/[4], not the headline.  "
-                         "f32x6 (experimental): fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulation")
+                         "f32x6 (experimental): fp32 operands split exactly into three bf16 pieces, six bf16 MFMA products, fp32 accumulation.  "
+                         "bf16cl: the bf16 DATA path of BASELINE configs[2]/[4] — activations and gradients bf16 channels-last in HBM, fp32 master "
+                         "weights / statistics / optimiser (dcvgan_amd/ops_cl.py)")
     ap.add_argument("--no-as-trainer", action="store_true", help="skip the secondary `as_trainer` key: the same iteration driven the way the reference's "
                                                                  "trainer.py drives it (4 host syncs on the losses, :326-328,363; a fresh pinned host batch "
                                                                  ".to(device) per iteration, :293-297), timed AFTER the headline region")
@@ -170,6 +172,11 @@ def dominant_kernel_probe(models, cfg, dev):
     F_ = cfg.batchsize * cfg.video_length
     x = torch.randn(F_, conv.in_channels, 32, 32, device=dev)
     g = layers.geom_of(conv)
+    from dcvgan_amd import ops_cl
+    if ops_cl.active():       # the same layer on the bf16 channels-last path
+        with torch.no_grad():
+            x = ops_cl.from_f32(x)
+        ops = ops_cl
     with torch.no_grad():
         for _ in range(3):
             ops.conv(x, conv.weight, g)     # the first call also packs the weights (cached afterwards, as in the step)
@@ -322,8 +329,13 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(CONFIGS[a.config], a.cpu_batch, a.cpu_steps)
 
-    native.set_precision(a.precision)
-    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    if a.precision == "bf16cl":
+        from dcvgan_amd import ops_cl
+        ops_cl.enable(True)
+    else:
+        native.set_precision(a.precision)
+    # f32x6 runs on the bf16 pipe with six products per fp32 product: its roofline is the bf16 peak / 6 (the weight gradients stay on the fp32 pipe)
+    peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "f32x6": PEAK_BF16_MFMA_TFLOPS / 6.0}.get(a.precision, PEAK_BF16_MFMA_TFLOPS)
     torch.manual_seed(cfg.seed)  # identical init on every rank, then made exact by a broadcast
     models = trainer.build_models(cfg, dev)
     for m in models.values():
@@ -426,9 +438,11 @@ def main():
         line = {
             "metric": "videos/sec per G+D step, 16x64x64 RGB+depth" if cfg.channel == 1 else "videos/sec per G+D step, 16x64x64 RGB+flow",
             "value": vps, "unit": "videos/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.precision == "fp32" else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "f32x6": "f32 (emulated: 3 x bf16 split, 6 products)"}.get(a.precision, "bf16"), "data": "synthetic",
             "config": {"workload": f"config/{a.config}.yml G+D iteration (trainer.py:279-363), as-written schedule, "
-                                   + ("fp32" if a.precision == "fp32" else "bf16 MFMA products / fp32 accumulation, storage, statistics and optimiser (throughput mode)") + gating,
+                                   + {"fp32": "fp32", "bf16": "bf16 MFMA products / fp32 accumulation, storage, statistics and optimiser (throughput mode)",
+                                      "f32x6": "fp32 emulated on the bf16 matrix pipe in the forward / data-gradient GEMMs (3-way bf16 split, six products, fp32 accumulation; experimental)",
+                                      "bf16cl": "bf16 channels-last DATA path: bf16 activations and gradients in HBM, fp32 master weights / statistics / accumulation / optimiser (throughput mode)"}[a.precision] + gating,
                        "per_gpu_batch": B, "global_batch": B * world, "clip": f"16x64x64 RGB + {cfg.channel}-channel {cfg.geometric_info}",
                        "parallelism": f"dp{world}", "hip_launches_per_step": launches // max(1, a.steps + a.warmup),
                        "rank0_cpus": sorted(os.sched_getaffinity(0)) if len(os.sched_getaffinity(0)) <= 64 else len(os.sched_getaffinity(0)),

@@ -101,7 +101,7 @@ struct ClGatherArgs {
     const __bf16* wp;            // [step][OCp][32] bf16
     int32_t M, OCp, nsteps, T;   // positions, padded output channels (multiple of the tile's), 32-deep K steps, taps
     int32_t cblk, y_c;           // 32-channel blocks per tap (0 = thin); channels to store (destination channels, multiple of 4)
-    int32_t x_cmax, pad0;        // bytes of one pixel's valid channels (granules past it are padding)
+    int32_t x_cmax, pad0;        // bytes of one pixel's own channels, rounded up to a granule (granules past them read as zeros)
     FastDiv div_sp, div_hw, div_w;
     ClDim td, th, tw;
     int64_t x_sn, y_sn;          // element strides
@@ -196,7 +196,6 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
                 const uint32_t ok = (md >> (sel & 3)) & (mh >> ((sel >> 2) & 3)) & (mw >> ((sel >> 4) & 3)) & 1u;
                 vm |= (uint64_t)ok << t;
             }
-            if (!THIN && 16 * c >= a.x_cmax) vm = 0;     // (never happens: whole 32-channel blocks) kept for symmetry
         }
         xbase[s] = base;
         xmask[s] = vm;
@@ -226,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
             const int tap_ = st_ / a.cblk, cb_ = st_ - tap_ * a.cblk;                                                         \
             const uint32_t to_ = (uint32_t)a.toff[tap_];                                                                      \
             _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                                 \
-                const uint32_t ok_ = (uint32_t)(xmask[s] >> tap_) & 1u;                                                       \
+                /* granules past the operand's own channels (a 16- or 24-channel slice of a wider buffer) are padding, not the neighbour's data */ \
+                const uint32_t ok_ = ((uint32_t)(xmask[s] >> tap_) & 1u) & (uint32_t)(cb_ * 64 + 16 * xchunk[s] < a.x_cmax);   \
                 const uint32_t vo_ = ok_ ? xbase[s] + to_ : 0xffffffffu;                                                      \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, vo_, cb_ * 64, 0, 0); \
             }                                                                                                                 \
@@ -775,7 +775,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
         a.cblk = thin ? 0 : Cp / 32;
         a.nsteps = thin ? (T + 3) / 4 : T * (Cp / 32);
         a.y_c = ocs;
-        a.x_cmax = 2 * (thin ? 8 : Cp);
+        a.x_cmax = 2 * pad8(pl.RC);
         a.div_sp = make_fastdiv((uint32_t)(c.o_ext[0] * c.o_ext[1] * c.o_ext[2]));
         a.div_hw = make_fastdiv((uint32_t)(c.o_ext[1] * c.o_ext[2]));
         a.div_w = make_fastdiv((uint32_t)c.o_ext[2]);

@@ -3362,14 +3362,18 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     // ... and only the 64-row tile takes it: its 48 row DMAs per 64 MFMAs are what bounds it (cgen.down0 1.351 -> 1.286 ms, gdis.5 0.355 -> 0.353), while
     // the MFMA-bound 128 x 128 tile measured 4-6 % SLOWER with it (the 2-way conflicts of the swizzled fragment reads; profiles/r03_ab_wgrad_d16.txt)
     const bool d16 = !toggles().no_wgrad_d16 && tc.bd == 64 && dd.sw == 1 && dd.w % 4 == 0 && dd.sh % 4 == 0 && dd.sd % 4 == 0 && dd.sn % 4 == 0 && dd.sc % 4 == 0 &&
-                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && eff_precision() == 0;
+                     (reinterpret_cast<uintptr_t>(D) % 16) == 0 && M64 % 4 == 0 && chunk % 4 == 0 && eff_precision() != 1 && !(eff_precision() == 2 && getenv("DCV_WGRAD_X6"));
     {
-        const int wbf = eff_precision();
+        const int wbf = eff_precision() == 2 && getenv("DCV_WGRAD_X6") == nullptr ? 0 : eff_precision();
         if (dma && a.log2nd >= 0) DCV_NOTE_KERNEL("wgrad_dma_kernel<%d, %d, %s> (%d x %d tile, %d slabs%s)", tc.bd == 128 ? 2 : 1, wbf, d16 ? "true" : "false", tc.bd, tc.bj, S2,
                                                   wbf == 2 ? ", f32x6: fp32 on the bf16 pipe" : wbf ? ", bf16 products" : "");
         else DCV_NOTE_KERNEL("wgrad_gemm_kernel (%d x %d tile, %d slabs)", tc.bd, tc.bj, S2);
     }
-    if (dma && a.log2nd >= 0 && eff_precision() == 2) {
+    // fp32 on the bf16 pipe (precision 2): the weight gradient keeps the native fp32 MFMA kernel unless DCV_WGRAD_X6 is set — both of its operands are
+    // activations, so both are split in registers (176 vector operations per 24 MFMAs): measured 112-128 TFLOP/s against the native kernel's 120-135
+    // (profiles/r04_f32x6_layers.csv); the gather kernels, whose weights arrive pre-split, gain 1.4-1.5x
+    static const bool wgrad_x6 = getenv("DCV_WGRAD_X6") != nullptr;
+    if (dma && a.log2nd >= 0 && eff_precision() == 2 && wgrad_x6) {
         if (tc.bd == 128) hipLaunchKernelGGL((wgrad_dma_kernel<2, 2>), dim3(tiles, S2), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((wgrad_dma_kernel<1, 2>), dim3(tiles, S2), dim3(256), 0, stream, a);
     } else if (dma && a.log2nd >= 0 && eff_precision() == 1) {

@@ -101,7 +101,7 @@ def test_conv_cl16_into_concat_slices_and_accumulated_fp32_boundary():
     from dcvgan_amd import native, ops, ops_cl
     native.lib()
     g = torch.Generator().manual_seed(5)
-    B, T = 2, 3
+    B, T = 2, 6
     vid = r16(torch.randn(B, T, 3, 16, 16, generator=g)).permute(0, 2, 1, 3, 4)         # non-contiguous (B,3,T,16,16) view, as generator.py:433 returns
     geo = r16(torch.randn(B, 1, T, 16, 16, generator=g))
     wc = r16(torch.randn(32, 3, 4, 4, 4, generator=g) * 0.1); wg = r16(torch.randn(32, 1, 4, 4, 4, generator=g) * 0.1)

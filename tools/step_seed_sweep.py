@@ -68,8 +68,13 @@ def main():
                 except AssertionError as e:
                     ok = False; fails += 1
                     print("  FAIL", str(e)[:300])
+                m1 = max(x.get("moment_rel", 0.0) for x in rows); m2 = max(x.get("moment2_rel", 0.0) for x in rows)
+                wk = SC.worst(rows, "rel_l2")[1]
+                kw = res.get("kink_worst_call")
                 print(f"{name:15s} seed {seed} it {it}: update {w:.2e} loss {res['loss_rel']:.1e} buffers {res['buffers_rel']:.1e} kinks {res['kink_flips']}/{res['kink_total']} far {res['kink_far']:.1e} "
-                      f"sensitive {ns} off {no} (worst tensor {per_row:.3f}) worst/lr/call {wl:.2f} {'ok' if ok else 'FAIL'}", flush=True)
+                      f"sensitive {ns} off {no} (worst tensor {per_row:.3f}) worst/lr/call {wl:.2f} moments {m1:.1e} {m2:.1e} {'ok' if ok else 'FAIL'} | worst update {wk[0]}/{wk[1]} | "
+                      f"furthest kink: call {kw[0] if kw else -1} shape {kw[4] if kw else ()} at {kw[5] if kw else None}", flush=True)
+                worst["moment_rel"] = max(worst.get("moment_rel", 0.0), m1); worst["moment2_rel"] = max(worst.get("moment2_rel", 0.0), m2)
                 worst["update_rel_l2"] = max(worst["update_rel_l2"], w); worst["loss_rel"] = max(worst["loss_rel"], res["loss_rel"])
                 worst["buffers_rel"] = max(worst["buffers_rel"], res["buffers_rel"]); worst["kink_far"] = max(worst["kink_far"], res["kink_far"])
                 worst["kink_frac"] = max(worst["kink_frac"], res["kink_flips"] / max(1, res["kink_total"])); worst["sens_off_frac"] = max(worst["sens_off_frac"], per_row)
