@@ -9,15 +9,15 @@ import torch
 from . import ops, util
 
 
-class HostMirroredLoss(torch.Tensor):
-    """The 0-d device tensor a loss method returns, plus an asynchronous host copy of its value.
+class HostMirroredLoss:
+    """Gives the 0-d device tensor a loss method returns an asynchronous host copy of its value.
 
     The reference trainer reads every loss with ``loss.cpu().item()`` AFTER the backward pass and the optimiser steps of the same phase
     (trainer.py:318-328, 355-363).  A plain ``.cpu()`` is a stream-ordered copy: the host would wait for that whole backward + Adam and the
     GPU would then sit idle while the host enqueues the next phase (measured: +2.2 % per iteration).  The value itself exists as soon as the
-    loss kernels have run, so it is copied to pinned host memory right then, on a side stream behind an event; ``.cpu()`` waits for THAT event
-    only and returns the host value.  Everything else (``+``, ``.backward()``, ``.detach_()``, autograd) is the plain tensor's behaviour; the
-    result of arithmetic on two such tensors carries no mirror and falls back to the ordinary copy."""
+    loss kernels have run, so it is copied to pinned host memory right then, on a side stream behind an event, and the tensor OBJECT gets a
+    ``cpu`` attribute that waits for THAT event only and returns the host value.  The tensor stays a plain torch.Tensor — ``+``, ``.backward()``,
+    ``.detach_()`` (trainer.py:324,361) and autograd see nothing unusual; a tensor computed from it carries no mirror and copies the ordinary way."""
 
     _side = {}
 
@@ -29,7 +29,6 @@ class HostMirroredLoss(torch.Tensor):
         side = HostMirroredLoss._side.get(dev.index)
         if side is None:
             side = HostMirroredLoss._side[dev.index] = torch.cuda.Stream(dev)
-        out = t.as_subclass(HostMirroredLoss)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         host = torch.empty((), dtype=t.dtype, pin_memory=True)
@@ -40,15 +39,15 @@ class HostMirroredLoss(torch.Tensor):
             done = torch.cuda.Event()
             done.record(side)
         src.record_stream(side)
-        out._mirror = (host, done)
-        return out
+        plain_cpu = t.cpu
 
-    def cpu(self, *args, **kwargs):
-        m = getattr(self, "_mirror", None)
-        if m is None or args or kwargs:
-            return super().cpu(*args, **kwargs)
-        m[1].synchronize()
-        return m[0].clone()
+        def cpu(*args, **kwargs):
+            if args or kwargs:
+                return plain_cpu(*args, **kwargs)
+            done.synchronize()
+            return host.clone()
+        t.cpu = cpu          # instance attribute: shadows torch.Tensor.cpu for this object only
+        return t
 
 
 class Loss(object):

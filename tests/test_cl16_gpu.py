@@ -180,8 +180,10 @@ def test_noise_and_activation_cl16():
 
 @pytest.mark.parametrize("name", ["surreal-depth1", "isogd-flow", "isogd-depth"])
 def test_models_cl16_against_fp32_path(name):
-    """Every model of a config at test width (ngf = ndf = 16 .. 24), same weights and random draws: the CL16 path's outputs within 3e-2 of the fp32 HIP
-    path's (bf16 storage of ~20 layers' activations), parameter gradients of a generator-loss backward within 6e-2 relative L2 per model."""
+    """Every model of a config at a quarter of its width, same weights and random draws (the discriminators' Noise layers switched off for this
+    comparison: the two paths index their Philox streams differently, so their noise realisations differ): the CL16 path's outputs within 3e-2 / 5e-2 of
+    the fp32 HIP path's (bf16 storage of ~20 layers' activations), parameter gradients of a generator-loss backward within 1e-1 relative L2 per model."""
+    import os
     from dcvgan_amd import native, ops_cl, trainer
     from dcvgan_amd.configs import CONFIGS
     from dcvgan_amd.rng import PhiloxRng
@@ -189,6 +191,10 @@ def test_models_cl16_against_fp32_path(name):
     cfg = CONFIGS[name].scaled(batchsize=2, width_div=4)
     torch.manual_seed(3)
     models = trainer.build_models(cfg, DEV)
+    for m in models.values():
+        for sub in m.modules():
+            if hasattr(sub, "use_noise"):
+                sub.use_noise = False
     loss = trainer.build_loss(cfg)
 
     def run():
@@ -210,15 +216,22 @@ def test_models_cl16_against_fp32_path(name):
         n0 = native.launch_count()
         got = run()
         assert native.launch_count() - n0 > 100
-        assert "cl_" in native.lib().dcv_debug_last_kernel().decode() or True
     finally:
         ops_cl.enable(False)
     assert got[0].dtype == torch.float32 and got[0].shape == ref[0].shape and got[0].stride() == ref[0].stride()      # the boundary is unchanged
-    assert rel(got[0], ref[0]) < 3e-2 and rel(got[1], ref[1]) < 3e-2, (rel(got[0], ref[0]), rel(got[1], ref[1]))
-    for a, b in zip(got[2], ref[2]):
-        assert a.shape == b.shape and rel(a, b) < 5e-2, rel(a, b)
+    rep = {"xg": rel(got[0], ref[0]), "xc": rel(got[1], ref[1])}
+    for k, a, b in zip(("y_idis", "y_vdis", "y_gdis"), got[2], ref[2]):
+        assert a.shape == b.shape
+        rep[k] = rel(a, b)
     for n in ref[3]:
-        assert rel(got[3][n], ref[3][n]) < 1e-1, (n, rel(got[3][n], ref[3][n]))
+        rep["grad_" + n] = rel(got[3][n], ref[3][n])
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, f"cl16_models_{name}.txt"), "w") as f:
+            f.write("\n".join(f"{k} {v:.3e}" for k, v in rep.items()) + "\n")
+    assert rep["xg"] < 3e-2 and rep["xc"] < 3e-2, rep
+    assert max(rep[k] for k in ("y_idis", "y_vdis", "y_gdis")) < 5e-2, rep
+    assert max(v for k, v in rep.items() if k.startswith("grad_")) < 1e-1, rep
 
 
 @pytest.mark.parametrize("name", ["surreal-depth1", "isogd-flow"])
@@ -249,5 +262,5 @@ def test_training_iteration_cl16(name):
         for n, m in models.items():
             after = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
             assert float((after != before[n]).float().mean()) > 0.5, n
-    for k in outs[True]:
-        assert abs(outs[True][k] - outs[False][k]) < 5e-2 * max(1.0, abs(outs[False][k])), (k, outs[True][k], outs[False][k])
+    for k in outs[True]:   # (isogd-flow's discriminators add noise, and the two paths draw different realisations: 15 % instead of 5 %)
+        assert abs(outs[True][k] - outs[False][k]) < (5e-2 if name == "surreal-depth1" else 1.5e-1) * max(1.0, abs(outs[False][k])), (k, outs[True][k], outs[False][k])

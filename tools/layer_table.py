@@ -26,7 +26,7 @@ ap.add_argument("--csv", default="")
 ap.add_argument("--filter", default="")
 ap.add_argument("--plan", default="")
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6"])
+ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6", "bf16cl"])
 a = ap.parse_args()
 cfg = CONFIGS[a.config]
 B = a.batch or cfg.batchsize
@@ -91,9 +91,15 @@ def timeit(fn, reps):
 
 
 Lb = lib()
-N.set_precision(a.precision)
-if a.precision == "bf16":
+CL = a.precision == "bf16cl"
+if CL:
+    from dcvgan_amd import ops_cl
+else:
+    N.set_precision(a.precision)
+if a.precision in ("bf16", "bf16cl"):
     PEAK = 16 * 157.3
+if a.precision == "f32x6":
+    PEAK = 16 * 157.3 / 6
 rows, plan = [], []
 tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
 totf = 0.0
@@ -105,14 +111,22 @@ for (name, tr, cin, cout, k, s, p, xs, nf, nd, nw) in L:
     w = torch.randn(((cin, cout) if tr else (cout, cin)) + k, device=dev) * 0.05
     g = ops.conv_geom(w, s, p, tr)
     with torch.no_grad():
-        y = ops.conv(x, w, g)
-    dy = torch.randn_like(y)
+        if CL:      # bf16 channels-last operands (ops_cl); the packed bf16 weights are made once, as once per optimiser step in the iteration
+            x = ops_cl.from_f32(x)
+            y = ops_cl.conv(x, w, g)
+            dy = ops_cl.from_f32(torch.randn(y.shape, device=dev))
+        else:
+            y = ops.conv(x, w, g)
+            dy = torch.randn_like(y)
     xd, yd = dims5(x), dims5(y)
     taps = k[0] * k[1] * (k[2] if len(k) == 3 else 1)
     macs = (x.numel() // cin if tr else y.numel() // cout) * cin * cout * taps
     gf = 2 * macs / 1e9
-    dx = torch.empty_like(x); dw_ = torch.empty_like(w)
+    dx = ops_cl.cl_empty(x.shape, dev) if CL else torch.empty_like(x); dw_ = torch.empty_like(w)
     packs = {}
+    if CL:
+        dxd = dims5(dx)
+        pk0 = ops_cl._packed(w, 0, g, xd, yd, tuple(x.shape)); pk1 = ops_cl._packed(w, 1, g, dxd, yd, tuple(x.shape))
 
     def pack(which):      # the step caches the packed weights between optimiser steps: so does the table
         if which not in packs:
@@ -122,6 +136,16 @@ for (name, tr, cin, cout, k, s, p, xs, nf, nd, nw) in L:
         pk = packs[which][1]
         ref = C.byref(pk)
         return pk, ref
+
+    def fwd_cl():
+        N.check(Lb.dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk0), ptr(y), C.byref(yd), 0, 0.0, stream_ptr()), "f")
+
+    def dgrad_cl():
+        N.check(Lb.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(yd), ptr(pk1), ptr(dx), C.byref(dxd), 0, stream_ptr()), "d")
+
+    def wgrad_cl():
+        need = Lb.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd)); wsp, wsn = ops._ws("clconv", need, dev)
+        N.check(Lb.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(yd), ptr(dw_), wsp, wsn, stream_ptr()), "w")
 
     def fwd():
         need = Lb.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0); wsp, wsn = ops._ws("conv", need, dev)
@@ -140,7 +164,7 @@ for (name, tr, cin, cout, k, s, p, xs, nf, nd, nw) in L:
         N.check(Lb.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(yd), ptr(dw_), wsp, wsn, stream_ptr()), "w")
 
     line = [name, gf]
-    for op, fn, cnt in (("fwd", fwd, nf), ("dgrad", dgrad, nd), ("wgrad", wgrad, nw)):
+    for op, fn, cnt in (("fwd", fwd_cl if CL else fwd, nf), ("dgrad", dgrad_cl if CL else dgrad, nd), ("wgrad", wgrad_cl if CL else wgrad, nw)):
         if a.plan:
             fn(); torch.cuda.synchronize()      # packs / tables built outside the counted launches
             n0 = N.launch_count()
