@@ -4,6 +4,8 @@
 // 16-byte group of 8 channels of a pixel, so a wave reads and writes whole 128-byte lines when C >= 64.  Statistics and parameters are fp32.
 #include "dcv_common.h"
 
+#include <algorithm>
+
 namespace dcv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -232,15 +234,30 @@ __global__ __launch_bounds__(256) void cl_bn_stats_kernel(const ClBnArgs a) {
     cl_bn_block_out<2>(s, a, g, p, PB, red);
 }
 
-// mean / invstd / running statistics from the partials (training) — one thread per channel, fp64, fixed order
-__global__ void cl_bn_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, double count, float eps, float momentum,
-                                      float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
-                                      float* __restrict__ mean, float* __restrict__ invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// sum of the partials of one channel and one value: fixed order (thread t sums blocks t, t + 256, ...; then a fixed tree over the 256 threads)
+__device__ __forceinline__ double cl_partial_sum(const double* __restrict__ partial, int nblocks, int C, int c, int v, int NV, double* red) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[((int64_t)b * C + c) * NV + v];
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+// mean / invstd / running statistics from the partials (training) — one 256-thread workgroup per channel, fp64, fixed order
+__global__ __launch_bounds__(256) void cl_bn_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, double count, float eps, float momentum,
+                                                             float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                                             float* __restrict__ mean, float* __restrict__ invstd) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    const double s1 = cl_partial_sum(partial, nblocks, C, c, 0, 2, red), s2 = cl_partial_sum(partial, nblocks, C, c, 1, 2, red);
+    if (threadIdx.x != 0) return;
     if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s1 += partial[((int64_t)b * C + c) * 2]; s2 += partial[((int64_t)b * C + c) * 2 + 1]; }
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -265,26 +282,36 @@ __global__ void cl_bn_coeff_kernel(int C, const float* __restrict__ gamma, const
     shift[c] = beta[c] - m * gamma[c] * is;
 }
 
+// thread (p, g) of a block: 8 channels of group g, pixels p + PB (blockIdx.x + k gridDim.x): per-channel parameters live in registers
 __global__ __launch_bounds__(256) void cl_bn_apply_kernel(const ClBnArgs a, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t pg = (uint32_t)(i / a.G);
-    const int g = (int)(i - (int64_t)pg * a.G);
-    const uint32_t n = fdiv(pg, a.div_pix), pix = pg - n * a.div_pix.div;
-    float v[8], o[8];
-    cl_unpack(cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8), v);
+    (void)total;
+    const int PB = a.pb, g = threadIdx.x % a.G, p = threadIdx.x / a.G;
+    if (p >= PB) return;
+    float sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = g * 8 + e;
-        float z = 0.f;
-        if (c < a.C) {
-            z = v[e] * a.scale[c] + a.shift[c];
-            if (a.mask) z *= a.mask[(int64_t)n * a.C + c];
-            if (a.act == DCV_ACT_LEAKY) z = z > 0.f ? z : z * a.slope;
+    for (int e = 0; e < 8; ++e) { sc[e] = a.scale[g * 8 + e]; sh[e] = a.shift[g * 8 + e]; }
+    const bool leaky = a.act == DCV_ACT_LEAKY;
+    const float slope = a.slope;
+    const int64_t stride = (int64_t)gridDim.x * PB;
+    for (int64_t q = (int64_t)blockIdx.x * PB + p; q < a.P; q += 2 * stride) {
+        const int64_t q1 = q + stride;
+        const bool two = q1 < a.P;
+        const uint32_t n0 = fdiv((uint32_t)q, a.div_pix), px0 = (uint32_t)q - n0 * a.div_pix.div;
+        const uint32_t n1 = two ? fdiv((uint32_t)q1, a.div_pix) : n0, px1 = two ? (uint32_t)q1 - n1 * a.div_pix.div : px0;
+        const u32x4 w0 = cl_ld(a.x + (int64_t)n0 * a.xv.sn + (int64_t)px0 * a.xv.pitch + g * 8);
+        const u32x4 w1 = cl_ld(a.x + (int64_t)n1 * a.xv.sn + (int64_t)px1 * a.xv.pitch + g * 8);
+        float v0[8], v1[8];
+        cl_unpack(w0, v0); cl_unpack(w1, v1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float z0 = v0[e] * sc[e] + sh[e], z1 = v1[e] * sc[e] + sh[e];
+            if (a.mask) { z0 *= a.mask[(int64_t)n0 * a.C + g * 8 + e]; z1 *= a.mask[(int64_t)n1 * a.C + g * 8 + e]; }
+            if (leaky) { z0 = z0 > 0.f ? z0 : z0 * slope; z1 = z1 > 0.f ? z1 : z1 * slope; }
+            v0[e] = z0; v1[e] = z1;
         }
-        o[e] = z;
+        cl_st(a.y + (int64_t)n0 * a.yv.sn + (int64_t)px0 * a.yv.pitch + g * 8, cl_pack(v0));
+        if (two) cl_st(a.y + (int64_t)n1 * a.yv.sn + (int64_t)px1 * a.yv.pitch + g * 8, cl_pack(v1));
     }
-    cl_st(a.y + (int64_t)n * a.yv.sn + (int64_t)pix * a.yv.pitch + g * 8, cl_pack(o));
 }
 
 // backward pass 1: per channel sum(dz), sum(dz * xhat) with dz = dy * act'(z) * mask, z = mask * (x scale + shift), xhat = (x - mean) invstd
@@ -332,13 +359,13 @@ __global__ __launch_bounds__(256) void cl_bn_bwd_reduce_kernel(const ClBnArgs a)
 // dgamma = sum(dz xhat), dbeta = sum(dz); coefficients of the apply pass: dx = k1 * dz - k2 - k3 * x  with
 //   training: dx = gamma invstd (dz - mean(dz) - xhat mean(dz xhat)):  k1 = gamma invstd, k3 = k1 invstd mean(dz xhat), k2 = k1 mean(dz) - k3 mean
 //   eval:     dx = gamma invstd dz
-__global__ void cl_bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, double count, int training,
-                                          const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s1 += partial[((int64_t)b * C + c) * 2]; s2 += partial[((int64_t)b * C + c) * 2 + 1]; }
+__global__ __launch_bounds__(256) void cl_bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, double count, int training,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2, float* __restrict__ k3) {
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    const double s1 = cl_partial_sum(partial, nblocks, C, c, 0, 2, red), s2 = cl_partial_sum(partial, nblocks, C, c, 1, 2, red);
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s1;
     dgamma[c] = (float)s2;
     const double a1 = (double)gamma[c] * invstd[c];
@@ -350,29 +377,31 @@ __global__ void cl_bn_bwd_finalize_kernel(const double* __restrict__ partial, in
     }
 }
 __global__ __launch_bounds__(256) void cl_bn_bwd_apply_kernel(const ClBnArgs a, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const uint32_t pg = (uint32_t)(i / a.G);
-    const int g = (int)(i - (int64_t)pg * a.G);
-    const uint32_t n = fdiv(pg, a.div_pix), pix = pg - n * a.div_pix.div;
-    float x[8], d[8], o[8];
-    cl_unpack(cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8), x);
-    cl_unpack(cl_ld(a.dy + (int64_t)n * a.dyv.sn + (int64_t)pix * a.dyv.pitch + g * 8), d);
+    (void)total;
+    const int PB = a.pb, g = threadIdx.x % a.G, p = threadIdx.x / a.G;
+    if (p >= PB) return;
+    float sc[8], sh[8], k1[8], k2[8], k3[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = g * 8 + e;
-        float r = 0.f;
-        if (c < a.C) {
+    for (int e = 0; e < 8; ++e) { const int c = g * 8 + e; sc[e] = a.scale[c]; sh[e] = a.shift[c]; k1[e] = a.c1[c]; k2[e] = a.c2[c]; k3[e] = a.c3[c]; }
+    const bool leaky = a.act == DCV_ACT_LEAKY;
+    const float slope = a.slope;
+    const int64_t stride = (int64_t)gridDim.x * PB;
+    for (int64_t q = (int64_t)blockIdx.x * PB + p; q < a.P; q += stride) {
+        const uint32_t n = fdiv((uint32_t)q, a.div_pix), pix = (uint32_t)q - n * a.div_pix.div;
+        float x[8], d[8];
+        cl_unpack(cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8), x);
+        cl_unpack(cl_ld(a.dy + (int64_t)n * a.dyv.sn + (int64_t)pix * a.dyv.pitch + g * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
             float mk = 1.f;
-            if (a.mask) mk = a.mask[(int64_t)n * a.C + c];
-            const float z = mk * (x[e] * a.scale[c] + a.shift[c]);
+            if (a.mask) mk = a.mask[(int64_t)n * a.C + g * 8 + e];
+            const float z = mk * (x[e] * sc[e] + sh[e]);
             float dz = d[e] * mk;
-            if (a.act == DCV_ACT_LEAKY) dz *= z > 0.f ? 1.f : a.slope;
-            r = a.c1[c] * dz - a.c2[c] - a.c3[c] * x[e];
+            if (leaky) dz *= z > 0.f ? 1.f : slope;
+            d[e] = k1[e] * dz - k2[e] - k3[e] * x[e];
         }
-        o[e] = r;
+        cl_st(a.y + (int64_t)n * a.yv.sn + (int64_t)pix * a.yv.pitch + g * 8, cl_pack(d));
     }
-    cl_st(a.y + (int64_t)n * a.yv.sn + (int64_t)pix * a.yv.pitch + g * 8, cl_pack(o));
 }
 
 // sample-linear view of a channels-last dims5 (pixel = (d, h, w) linear); false when the tensor is not of that form
@@ -506,7 +535,7 @@ int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv
     if (training) {
         hipLaunchKernelGGL(cl_bn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)a.C * 2 * sizeof(double), st, a);
         DCV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(cl_bn_finalize_kernel, dim3((unsigned)cb), dim3(64), 0, st, partial, blocks, a.C, (double)a.P, eps, momentum, running_mean, running_var,
+        hipLaunchKernelGGL(cl_bn_finalize_kernel, dim3((unsigned)a.C), dim3(256), 0, st, partial, blocks, a.C, (double)a.P, eps, momentum, running_mean, running_var,
                            num_batches_tracked, save_mean, save_invstd);
         DCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(cl_bn_coeff_kernel, dim3((unsigned)cb), dim3(64), 0, st, a.C, gamma, beta, save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, eps,
@@ -518,7 +547,7 @@ int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv
     }
     DCV_LAUNCH_CHECK();
     const int64_t total = a.P * a.G;
-    hipLaunchKernelGGL(cl_bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, total);
+    hipLaunchKernelGGL(cl_bn_apply_kernel, dim3((unsigned)std::min<int64_t>(std::max<int64_t>((a.P + (int64_t)a.pb * 4 - 1) / ((int64_t)a.pb * 4), 1), 8192)), dim3(256), 0, st, a, total);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -547,12 +576,12 @@ int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, 
     hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)a.C * 2 * sizeof(double), st, a);
     DCV_LAUNCH_CHECK();
     float* k1 = coef + 2 * a.C; float* k2 = coef + 3 * a.C; float* k3 = coef + 4 * a.C;
-    hipLaunchKernelGGL(cl_bn_bwd_finalize_kernel, dim3((unsigned)cb), dim3(64), 0, st, partial, blocks, a.C, (double)a.P, training, gamma, save_mean, save_invstd,
+    hipLaunchKernelGGL(cl_bn_bwd_finalize_kernel, dim3((unsigned)a.C), dim3(256), 0, st, partial, blocks, a.C, (double)a.P, training, gamma, save_mean, save_invstd,
                        dgamma, dbeta, k1, k2, k3);
     DCV_LAUNCH_CHECK();
     a.c1 = k1; a.c2 = k2; a.c3 = k3;
     const int64_t total = a.P * a.G;
-    hipLaunchKernelGGL(cl_bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, total);
+    hipLaunchKernelGGL(cl_bn_bwd_apply_kernel, dim3((unsigned)std::min<int64_t>(std::max<int64_t>((a.P + (int64_t)a.pb * 4 - 1) / ((int64_t)a.pb * 4), 1), 8192)), dim3(256), 0, st, a, total);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
