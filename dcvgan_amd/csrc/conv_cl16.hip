@@ -19,6 +19,7 @@
 #include "dcv_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace dcv {
@@ -581,6 +582,92 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduc
     a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
 }
 
+
+// --------------------------------------------------------------------------- //
+// Thin destinations (<= 8 channels: the RGB / depth / flow heads, the discriminators' last convolutions, data gradients into such tensors) fed by a wide
+// source.  As a gather GEMM their K loop re-reads the wide source once per tap for 32 mostly padded output columns (cgen.outconv: 9 x 1.7 GB through L2
+// for 3 channels, 2.0 ms).  Instead: ONE pass over the source as a 1x1 GEMM with the taps moved to the OUTPUT side,
+//     Z[src pixel][(tap, oc)] = sum_c X[src pixel][c] * w[oc, c, tap]        (cl_gather_kernel, single tap, T * OC columns)
+// and a cheap gather of the few values each destination pixel needs (col2im):
+//     y[dst][oc] = act( sum_{taps whose source pixel exists} Z[src(dst, tap)][(tap, oc)] ).
+// --------------------------------------------------------------------------- //
+struct ClPackThinArgs {
+    __bf16* wp;
+    int32_t nsteps, OCg, OCgp, C, OC, T;   // K steps (C / 32 blocks), T * OC GEMM columns, padded, source channels, real output channels, taps
+    int64_t ws_o, ws_r;
+};
+__global__ __launch_bounds__(256) void cl_pack_thin_kernel(const float* __restrict__ w, const ClPackThinArgs pa) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)pa.nsteps * pa.OCgp * 32;
+    if (i >= tot) return;
+    const int kk = (int)(i & 31), col = (int)((i >> 5) % pa.OCgp), step = (int)((i >> 5) / pa.OCgp);
+    const int c = step * 32 + kk;
+    float v = 0.f;
+    if (col < pa.OCg && c < pa.C) {
+        const int t = col / pa.OC, oc = col - t * pa.OC;
+        v = w[(int64_t)oc * pa.ws_o + (int64_t)c * pa.ws_r + t];
+    }
+    pa.wp[i] = (__bf16)v;
+}
+
+struct ClCol2imArgs {
+    const __bf16* z;
+    __bf16* y;
+    int32_t OC, zpitch, T, scatter;          // scatter: src = (dst + p - k) / s when divisible; else src = dst * s - p + k
+    int32_t k[3], s[3], p[3], sext[3];       // filter, stride, padding, source extents
+    int32_t dext[3], act;
+    FastDiv div_sp, div_hw, div_w;           // destination pixel decode
+    int64_t y_sn; int32_t y_sd, y_sh, y_sw;  // destination strides (elements)
+    int32_t s_sp, s_hw, s_w, accumulate;     // source pixel linearisation (Z is contiguous): n * s_sp + d * s_hw + h * s_w + w
+    float slope; int32_t pad;
+    int64_t total;
+};
+__global__ __launch_bounds__(256) void cl_col2im_kernel(const ClCol2imArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.total) return;
+    const uint32_t n = fdiv((uint32_t)i, a.div_sp);
+    uint32_t r = (uint32_t)i - n * a.div_sp.div;
+    const uint32_t od = fdiv(r, a.div_hw);
+    r -= od * a.div_hw.div;
+    const uint32_t oh = fdiv(r, a.div_w);
+    const uint32_t ow = r - oh * a.div_w.div;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int o[3] = {(int)od, (int)oh, (int)ow};
+    for (int kd = 0; kd < a.k[0]; ++kd) {
+        int id;
+        if (a.scatter) { const int q = o[0] + a.p[0] - kd; if (q < 0 || q % a.s[0]) continue; id = q / a.s[0]; } else id = o[0] * a.s[0] - a.p[0] + kd;
+        if ((unsigned)id >= (unsigned)a.sext[0]) continue;
+        for (int kh = 0; kh < a.k[1]; ++kh) {
+            int ih;
+            if (a.scatter) { const int q = o[1] + a.p[1] - kh; if (q < 0 || q % a.s[1]) continue; ih = q / a.s[1]; } else ih = o[1] * a.s[1] - a.p[1] + kh;
+            if ((unsigned)ih >= (unsigned)a.sext[1]) continue;
+            for (int kw = 0; kw < a.k[2]; ++kw) {
+                int iw;
+                if (a.scatter) { const int q = o[2] + a.p[2] - kw; if (q < 0 || q % a.s[2]) continue; iw = q / a.s[2]; } else iw = o[2] * a.s[2] - a.p[2] + kw;
+                if ((unsigned)iw >= (unsigned)a.sext[2]) continue;
+                const int t = (kd * a.k[1] + kh) * a.k[2] + kw;
+                const __bf16* zp = a.z + ((int64_t)n * a.s_sp + (int64_t)id * a.s_hw + (int64_t)ih * a.s_w + iw) * a.zpitch + t * a.OC;
+                for (int e = 0; e < a.OC; ++e) acc[e] += (float)zp[e];
+            }
+        }
+    }
+    __bf16* yp = a.y + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = e < a.OC ? acc[e] : 0.f;
+        if (a.accumulate && e < a.OC) t += (float)yp[e];
+        v[e] = e < a.OC ? cl_act(t, a.act, a.slope) : 0.f;
+    }
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    u32x4 o4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; o4[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2)); }
+    *reinterpret_cast<u32x4*>(yp) = o4;
+}
+
 struct ClTile { int bn, bm; };
 static ClTile cl_pick_tile(int OC) {
     if (OC > 64) return {128, 128};
@@ -628,6 +715,13 @@ static int cl_make_plan(int which, const dcv_conv_geom* g, const dcv_dims5* xd, 
     }
     return DCV_OK;
 }
+
+// thin destination fed by a wide source: the GEMM + col2im form (above)
+static bool cl_thin_out(const ClPlan& pl, const dcv_conv_geom* g) {
+    const int T = g->kd * g->kh * g->kw;
+    return pl.OC <= 8 && !cl_thin(pl.RC) && T * pl.OC <= 512 && getenv("DCV_CL_NO_COL2IM") == nullptr;
+}
+static inline int cl_pitch(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
 
 static int cl_check_tensor(const dcv_dims5& d, const char* tag) {
     if (d.c > 1 && d.sc != 1) return fail(DCV_EINVAL, "%s: channels-last tensor expected (channel stride 1, got %lld)", tag, (long long)d.sc);
@@ -689,9 +783,23 @@ extern "C" {
 size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
     ClPlan pl;
     if (!g || !x || !y || (which != 0 && which != 1) || cl_make_plan(which, g, x, y, &pl) != DCV_OK) return 0;
+    if (cl_thin_out(pl, g)) {
+        const int OCg = g->kd * g->kh * g->kw * pl.OC;
+        const ClTile tc = cl_pick_tile(OCg);
+        return align_up((size_t)(cl_cp(pl.RC) / 32) * ((OCg + tc.bn - 1) / tc.bn * tc.bn) * 64, 256) + 256;
+    }
     size_t tot = 0;
     for (const ClClass& c : pl.cls) tot += cl_class_pack_bytes(c, pl.RC, pl.OC);
     return tot + 256;
+}
+
+// scratch a forward / backward-data call needs (the Z tensor of the thin-destination form; 0 otherwise)
+size_t dcv_cl_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
+    ClPlan pl;
+    if (!g || !x || !y || (which != 0 && which != 1) || cl_make_plan(which, g, x, y, &pl) != DCV_OK) return 0;
+    if (!cl_thin_out(pl, g)) return 256;
+    const dcv_dims5& src = (which == 0) ? *x : *y;
+    return (size_t)src.n * src.d * src.h * src.w * cl_pitch(g->kd * g->kh * g->kw * pl.OC) * 2 + 512;
 }
 
 int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which, const float* w, void* packed, size_t bytes, void* stream) {
@@ -699,6 +807,21 @@ int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
     if (!g || !x || !y || !w || !packed) return fail(DCV_EINVAL, "cl_pack_weights: null pointer");
     int rc = cl_make_plan(which, g, x, y, &pl);
     if (rc != DCV_OK) return rc;
+    if (cl_thin_out(pl, g)) {
+        ClPackThinArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.T = g->kd * g->kh * g->kw; ta.OC = pl.OC; ta.OCg = ta.T * pl.OC; ta.C = pl.RC;
+        const ClTile tg = cl_pick_tile(ta.OCg);
+        ta.OCgp = (ta.OCg + tg.bn - 1) / tg.bn * tg.bn;
+        ta.nsteps = cl_cp(pl.RC) / 32;
+        ta.ws_o = pl.ws_o; ta.ws_r = pl.ws_r;
+        ta.wp = static_cast<__bf16*>(packed);
+        const int64_t tot = (int64_t)ta.nsteps * ta.OCgp * 32;
+        if ((size_t)tot * 2 > bytes) return fail(DCV_EWORKSPACE, "cl_pack_weights: buffer too small");
+        hipLaunchKernelGGL(cl_pack_thin_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, ta);
+        DCV_LAUNCH_CHECK();
+        return DCV_OK;
+    }
     const ClTile tc = cl_pick_tile(pl.OC);
     ClPackArgs pa;
     memset(&pa, 0, sizeof(pa));
@@ -731,8 +854,63 @@ int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
 }
 
 // which: 0 forward (x -> y), 1 backward-data (dy -> dx); src / dst are bf16 channels-last
+static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl, const void* src_p, const dcv_dims5& src, const void* packed, void* dst_p,
+                            const dcv_dims5& dst, int act, float slope, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int T = g->kd * g->kh * g->kw, OCg = T * pl.OC, zp = cl_pitch(OCg), Cp = cl_cp(pl.RC);
+    const int64_t Msrc = (int64_t)src.n * src.d * src.h * src.w;
+    if (Msrc >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: too many source pixels");
+    const size_t zbytes = (size_t)Msrc * zp * 2;
+    if (!ws || ws_bytes < zbytes) return fail(DCV_EWORKSPACE, "cl conv: workspace too small for the thin-destination form (%zu needed, %zu given)", zbytes, ws_bytes);
+    if (src.w > 1 && src.sw < Cp) return fail(DCV_EINVAL, "cl conv: source pixel pitch %lld < padded channels %d", (long long)src.sw, Cp);
+    if (dst.w > 1 && dst.sw < 8) return fail(DCV_EINVAL, "cl conv: thin destination needs a pixel pitch of 8");
+    const int64_t xb = cl_extent_bytes(src, Cp);
+    if (xb >= (1ll << 31) || zbytes >= (1ull << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: tensors beyond 2 GB");
+    const ClTile tc = cl_pick_tile(OCg);
+    const int OCgp = (OCg + tc.bn - 1) / tc.bn * tc.bn;
+    // (1) Z = X (1x1) Wg : every source pixel once
+    ClGatherPack pk;
+    memset(&pk, 0, sizeof(pk));
+    ClGatherArgs& a = pk.c[0];
+    a.x = static_cast<const __bf16*>(src_p); a.y = static_cast<__bf16*>(ws); a.wp = static_cast<const __bf16*>(packed);
+    a.M = (int)Msrc; a.OCp = OCgp; a.T = 1; a.cblk = Cp / 32; a.nsteps = Cp / 32; a.y_c = (OCg + 3) / 4 * 4; a.x_cmax = 2 * pad8(pl.RC);
+    a.div_sp = make_fastdiv((uint32_t)(src.d * src.h * src.w)); a.div_hw = make_fastdiv((uint32_t)(src.h * src.w)); a.div_w = make_fastdiv((uint32_t)src.w);
+    ClDim one;
+    memset(&one, 0, sizeof(one));
+    one.n = 1; one.mul = 1; one.base = 0;
+    a.td = one; a.td.size = src.d; a.th = one; a.th.size = src.h; a.tw = one; a.tw.size = src.w;
+    a.x_sn = src.sn; a.x_sd = (int32_t)src.sd; a.x_sh = (int32_t)src.sh; a.x_sw = (int32_t)src.sw;
+    a.y_sn = (int64_t)src.d * src.h * src.w * zp; a.y_sd = src.h * src.w * zp; a.y_sh = src.w * zp; a.y_sw = zp; a.y_off = 0;
+    a.act = DCV_ACT_NONE; a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)zbytes;
+    for (int i = 1; i < 4; ++i) pk.c[i] = pk.c[0];
+    pk.ncls = 1; pk.tiles_oc = OCgp / tc.bn; pk.tiles_m = (int)((Msrc + tc.bm - 1) / tc.bm);
+    const dim3 grid((unsigned)((pk.tiles_m + 7) / 8 * 8 * pk.tiles_oc));
+    if (tc.bn == 128) cl_launch_gather<2, 2, 2, 2>(pk, false, grid, st);
+    else if (tc.bn == 64) cl_launch_gather<2, 2, 1, 4>(pk, false, grid, st);
+    else cl_launch_gather<1, 2, 1, 4>(pk, false, grid, st);
+    DCV_LAUNCH_CHECK();
+    // (2) gather the taps of every destination pixel
+    ClCol2imArgs c;
+    memset(&c, 0, sizeof(c));
+    c.z = static_cast<const __bf16*>(ws); c.y = static_cast<__bf16*>(dst_p);
+    c.OC = pl.OC; c.zpitch = zp; c.T = T;
+    const bool direct = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
+    c.scatter = direct ? 0 : 1;
+    c.k[0] = g->kd; c.k[1] = g->kh; c.k[2] = g->kw; c.s[0] = g->sd; c.s[1] = g->sh; c.s[2] = g->sw; c.p[0] = g->pd; c.p[1] = g->ph; c.p[2] = g->pw;
+    c.sext[0] = src.d; c.sext[1] = src.h; c.sext[2] = src.w; c.dext[0] = dst.d; c.dext[1] = dst.h; c.dext[2] = dst.w;
+    c.act = act; c.slope = slope; c.accumulate = accumulate;
+    c.div_sp = make_fastdiv((uint32_t)(dst.d * dst.h * dst.w)); c.div_hw = make_fastdiv((uint32_t)(dst.h * dst.w)); c.div_w = make_fastdiv((uint32_t)dst.w);
+    c.y_sn = dst.sn; c.y_sd = (int32_t)dst.sd; c.y_sh = (int32_t)dst.sh; c.y_sw = (int32_t)dst.sw;
+    c.s_sp = src.d * src.h * src.w; c.s_hw = src.h * src.w; c.s_w = src.w;
+    c.total = (int64_t)dst.n * dst.d * dst.h * dst.w;
+    if (c.total >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: too many destination pixels");
+    hipLaunchKernelGGL(cl_col2im_kernel, dim3((unsigned)((c.total + 255) / 256)), dim3(256), 0, st, c);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile> as a 1x1 GEMM over the source + cl_col2im_kernel (thin destination, bf16 channels-last)", tc.bn, tc.bm);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, const dcv_dims5* xd, const void* packed, void* dst_p, const dcv_dims5* yd,
-                       int act, float slope, int accumulate, void* stream) {
+                       int act, float slope, int accumulate, void* ws, size_t ws_bytes, void* stream) {
     if (!g || !xd || !yd || !src_p || !packed || !dst_p) return fail(DCV_EINVAL, "cl conv: null pointer");
     ClPlan pl;
     int rc = cl_make_plan(which, g, xd, yd, &pl);
@@ -740,6 +918,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     const dcv_dims5& src = (which == 0) ? *xd : *yd;
     const dcv_dims5& dst = (which == 0) ? *yd : *xd;
     if ((rc = cl_check_tensor(src, "cl conv source")) != DCV_OK || (rc = cl_check_tensor(dst, "cl conv destination")) != DCV_OK) return rc;
+    if (cl_thin_out(pl, g)) return cl_conv_thin_out(which, g, pl, src_p, src, packed, dst_p, dst, act, slope, accumulate, ws, ws_bytes, static_cast<hipStream_t>(stream));
     const bool thin = cl_thin(pl.RC);
     const int Cp = cl_cp(pl.RC);
     // the gathered tensor's channel slice must be readable in whole K granules: pixel pitch >= padded channel count
@@ -808,12 +987,12 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
 }
 
 int dcv_cl_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
-                        int act, float slope, void* stream) {
-    return cl_conv_run(0, g, x, xd, packed, y, yd, act, slope, 0, stream);
+                        int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+    return cl_conv_run(0, g, x, xd, packed, y, yd, act, slope, 0, ws, ws_bytes, stream);
 }
 int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
-                              int accumulate, void* stream) {
-    return cl_conv_run(1, g, dy, dxd, packed, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, stream);
+                              int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return cl_conv_run(1, g, dy, dxd, packed, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream);
 }
 
 size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y) {

@@ -93,8 +93,9 @@ _SIGS = {
     "dcv_gru_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "dcv_cl_packed_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
     "dcv_cl_pack_weights": (C.c_int, [_G, _D, _D, C.c_int, _P, _P, C.c_size_t, _P]),
-    "dcv_cl_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P]),
-    "dcv_cl_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P]),
+    "dcv_cl_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
+    "dcv_cl_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_cl_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
     "dcv_cl_wgrad_workspace_bytes": (C.c_size_t, [_G, _D, _D]),
     "dcv_cl_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
     "dcv_cl_from_f32": (C.c_int, [_P, _D, _P, _D, _P]),

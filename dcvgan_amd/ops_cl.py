@@ -209,7 +209,8 @@ class _ConvCl(Function):
             raise N.NativeError(f"out= has shape {tuple(y.shape)}, expected {tuple(shape)}")
         xd, yd = dims5(x), dims5(y)
         pk = _packed(w, 0, g, xd, yd, tuple(x.shape))
-        check(lib().dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, stream_ptr()), "dcv_cl_conv_forward")
+        wsp, wsn = _ws("clconv", lib().dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0), x.device)
+        check(lib().dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_cl_conv_forward")
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -228,7 +229,8 @@ class _ConvCl(Function):
             dx = cl_empty(x.shape, x.device)
             dxd = dims5(dx)
             pk = _packed(w, 1, g, dxd, dyd, tuple(x.shape))
-            check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 0, stream_ptr()), "dcv_cl_conv_backward_data")
+            wsp, wsn = _ws("clconv", L.dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1), x.device)
+            check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 0, wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_data")
         if ctx.needs_input_grad[1]:
             dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
             need = L.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd))

@@ -266,10 +266,13 @@ int dcv_adam_step_multi(int n_tensors, float* const* p, const float* const* g, f
  * described by dcv_dims5 with element strides.  A throughput path with its own tolerance (tests/test_cl16_gpu.py), never the default. */
 size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which /*0 fwd, 1 bwd-data*/);
 int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which, const float* w, void* packed, size_t bytes, void* stream);
+/* scratch of a forward / backward-data call (thin destinations — <= 8 channels fed by a wide source — run as a 1x1 GEMM over the source followed by a gather
+ * of each destination pixel's taps, and keep the GEMM's result there) */
+size_t dcv_cl_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which);
 int dcv_cl_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
-                        int act, float slope, void* stream);
+                        int act, float slope, void* ws, size_t ws_bytes, void* stream);
 int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
-                              int accumulate, void* stream);
+                              int accumulate, void* ws, size_t ws_bytes, void* stream);
 size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
 int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
                                 void* ws, size_t ws_bytes, void* stream);

@@ -138,10 +138,12 @@ for (name, tr, cin, cout, k, s, p, xs, nf, nd, nw) in L:
         return pk, ref
 
     def fwd_cl():
-        N.check(Lb.dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk0), ptr(y), C.byref(yd), 0, 0.0, stream_ptr()), "f")
+        wsp, wsn = ops._ws("clconv", Lb.dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0), dev)
+        N.check(Lb.dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk0), ptr(y), C.byref(yd), 0, 0.0, wsp, wsn, stream_ptr()), "f")
 
     def dgrad_cl():
-        N.check(Lb.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(yd), ptr(pk1), ptr(dx), C.byref(dxd), 0, stream_ptr()), "d")
+        wsp, wsn = ops._ws("clconv", Lb.dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(yd), 1), dev)
+        N.check(Lb.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(yd), ptr(pk1), ptr(dx), C.byref(dxd), 0, wsp, wsn, stream_ptr()), "d")
 
     def wgrad_cl():
         need = Lb.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd)); wsp, wsn = ops._ws("clconv", need, dev)
