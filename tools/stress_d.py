@@ -1,5 +1,6 @@
 """32 x 128 x 128 discriminator stress shape (SURVEY §8(d) "D5"): vdis + gdis forward/backward on flow clips
-(Cg = 2), HIP-event timed.  Usage: python tools/stress_d.py [B]"""
+(Cg = 2), HIP-event timed.  Usage: python tools/stress_d.py [B] [fp32|bf16|f32x6|bf16cl]
+(bf16cl = the bf16 channels-last data path: BASELINE configs[4] names a 16-bit MFMA run of this shape)"""
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -8,6 +9,12 @@ from dcvgan_amd import discriminator as D, native
 native.lib()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+MODE = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+if MODE == "bf16cl":
+    from dcvgan_amd import ops_cl
+    ops_cl.enable(True)
+else:
+    native.set_precision(MODE)
 torch.manual_seed(0)
 vdis = D.VideoDiscriminator(2, 3, True, 0.2, 64).to(dev)
 gdis = D.GradientDiscriminator(2, 3, False, 0.2, 32).to(dev)
@@ -33,4 +40,4 @@ for _ in range(3):
 e1.record(); e1.synchronize()
 ms = e0.elapsed_time(e1) / 3
 gf = 3 * (55.1 + 13.6) * B   # fwd + dgrad + wgrad, SURVEY §8(d)
-print(f"B={B}: {ms:.2f} ms per fwd+bwd, ~{gf / ms:.1f} TFLOP/s, peak mem {torch.cuda.max_memory_allocated() / 1e9:.2f} GB")
+print(f"{MODE} B={B}: {ms:.2f} ms per fwd+bwd, ~{gf / ms:.1f} TFLOP/s, {B / ms * 1e3:.1f} clips/s, peak mem {torch.cuda.max_memory_allocated() / 1e9:.2f} GB")
