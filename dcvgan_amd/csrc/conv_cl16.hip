@@ -564,11 +564,16 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
 struct ClWgradReduceArgs {
     const float* slab;
     float* dw;
-    int32_t S, tiles, tiles_d, gblocks, gcb, ntpt, T, DC, GC;
+    int32_t S, tiles, tiles_d, gblocks, gcb, ntpt, T, DC, GC, lpe;
     int64_t ws_d;
 };
 __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduceArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // LPE lanes per output element (1, or 64 when there are many position splits: a thread walking 1000+ slabs 64 KB apart is a serial chain of
+    // cache misses); fixed order either way: lane l sums slabs l, l + LPE, ... and the lanes meet in a fixed xor tree
+    const int lpe = a.lpe;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = lpe == 1 ? gid : gid >> 6;
+    const int l = lpe == 1 ? 0 : (int)(threadIdx.x & 63);
     const int64_t tot = (int64_t)a.DC * a.GC * a.T;
     if (i >= tot) return;
     const int t = (int)(i % a.T), gc = (int)((i / a.T) % a.GC), dc = (int)(i / ((int64_t)a.T * a.GC));
@@ -578,19 +583,15 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduc
     const int vc = tl * a.gcb + (gc & 127);
     const float* p = a.slab + ((int64_t)tile * 128 + (dc & 127)) * 128 + vc;
     float s = 0.f;
-    for (int k = 0; k < a.S; ++k) s += p[(int64_t)k * a.tiles * (128 * 128)];
+    for (int k = l; k < a.S; k += lpe) s += p[(int64_t)k * a.tiles * (128 * 128)];
+    if (lpe > 1) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (l != 0) return;
+    }
     a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
 }
 
-
-// --------------------------------------------------------------------------- //
-// Thin destinations (<= 8 channels: the RGB / depth / flow heads, the discriminators' last convolutions, data gradients into such tensors) fed by a wide
-// source.  As a gather GEMM their K loop re-reads the wide source once per tap for 32 mostly padded output columns (cgen.outconv: 9 x 1.7 GB through L2
-// for 3 channels, 2.0 ms).  Instead: ONE pass over the source as a 1x1 GEMM with the taps moved to the OUTPUT side,
-//     Z[src pixel][(tap, oc)] = sum_c X[src pixel][c] * w[oc, c, tap]        (cl_gather_kernel, single tap, T * OC columns)
-// and a cheap gather of the few values each destination pixel needs (col2im):
-//     y[dst][oc] = act( sum_{taps whose source pixel exists} Z[src(dst, tap)][(tap, oc)] ).
-// --------------------------------------------------------------------------- //
 struct ClPackThinArgs {
     __bf16* wp;
     int32_t nsteps, OCg, OCgp, C, OC, T;   // K steps (C / 32 blocks), T * OC GEMM columns, padded, source channels, real output channels, taps
@@ -1061,7 +1062,8 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
         a.slab = slab; a.dw = dw; a.S = p.S; a.tiles = p.tiles; a.tiles_d = p.tiles_d; a.gblocks = p.gblocks; a.gcb = p.gcb; a.ntpt = p.ntpt; a.T = p.T;
         a.DC = D.c; a.GC = G.c; a.ws_d = (int64_t)G.c * p.T;
         const int64_t tot = (int64_t)D.c * G.c * p.T;
-        hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a);
+        a.lpe = (p.S >= 32 && tot * 64 < (1ll << 31)) ? 64 : 1;
+        hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((tot * a.lpe + 255) / 256)), dim3(256), 0, st, a);
         DCV_LAUNCH_CHECK();
     }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, bf16 channels-last)", p.tiles, p.S);
