@@ -765,9 +765,9 @@ static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_d
     p->tiles_d = (pad8(D.c) + 127) / 128;
     p->tiles_j = (p->T + p->ntpt - 1) / p->ntpt * p->gblocks;
     p->tiles = p->tiles_d * p->tiles_j;
-    // position splits: ~2048 workgroups (4 resident per CU, two rounds) however few tiles the op has — a thin operand's single tile would otherwise run as one
-    // workgroup per CU, bound by the latency of its own DMAs (cgen.inconv 0.91 ms) —, at least 16 K steps (512 positions) each
-    static const int64_t target = getenv("DCV_CL_WGRAD_WGS") ? atoll(getenv("DCV_CL_WGRAD_WGS")) : 2048;
+    // position splits: ~1024 workgroups (one round of 4 per CU) however few tiles the op has, at least 16 K steps (512 positions) each; measured over the
+    // surreal-depth1 layer table: 13.8 ms of weight gradients per iteration at 1024, 15.9 at 2048, 20.1 at 4096 (slab traffic)
+    static const int64_t target = getenv("DCV_CL_WGRAD_WGS") ? atoll(getenv("DCV_CL_WGRAD_WGS")) : 1024;
     int64_t S = (target + p->tiles - 1) / p->tiles;
     const int64_t maxS = std::max<int64_t>(1, p->M / 512);
     S = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S, maxS), 2048));
