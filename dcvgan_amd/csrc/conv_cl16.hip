@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace dcv {
@@ -742,6 +744,15 @@ static void cl_launch_gather(const ClGatherPack& pk, bool thin, dim3 grid, hipSt
 }
 
 
+// The position table of a weight-gradient call depends on the geometry and the two tensors' shapes / strides only: built once per (device, key) and kept
+// (16 bytes per dense position; the iteration's ~30 distinct layers hold ~0.5 GB at B = 100).  DCV_CL_NO_POSTAB_CACHE=1: rebuild into the workspace per call.
+struct ClTabKey {
+    int dev; int32_t v[24]; int64_t w[4];
+    bool operator<(const ClTabKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+static std::mutex g_tab_mu;
+static std::map<ClTabKey, ClPosEntry*> g_tabs;
+
 static bool cl_pixel_linear(const dcv_dims5& d, int64_t* pitch) {
     int64_t p = 0;
     if (d.w > 1) p = d.sw; else if (d.h > 1) p = d.sh; else if (d.d > 1) p = d.sd; else if (d.n > 1) p = d.sn; else p = pad8(d.c);
@@ -928,7 +939,9 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     const int Cp = cl_cp(pl.RC);
     // the gathered tensor's channel slice must be readable in whole K granules: pixel pitch >= padded channel count
     if (src.w > 1 && src.sw < (thin ? 8 : Cp)) return fail(DCV_EINVAL, "cl conv: source pixel pitch %lld < padded channels %d", (long long)src.sw, thin ? 8 : Cp);
-    const int ocs = (pl.OC + 3) / 4 * 4;      // stores are 4-channel groups: the destination's pixel pitch must have room for them
+    // stores are 4-channel groups; a destination that owns its whole pixel (not a channel slice of a wider buffer) gets all pad8(OC) channels written —
+    // zeros past OC — so nobody has to clear a fresh tensor's padding channels first
+    const int ocs = (dst.w > 1 ? dst.sw : pad8(pl.OC)) >= pad8(pl.OC) && pl.OC % 8 ? pad8(pl.OC) : (pl.OC + 3) / 4 * 4;
     if (dst.w > 1 && dst.sw < ocs) return fail(DCV_EINVAL, "cl conv: destination pixel pitch %lld < %d stored channels", (long long)dst.sw, ocs);
     const ClTile tc = cl_pick_tile(pl.OC);
     const int OCp = (pl.OC + tc.bn - 1) / tc.bn * tc.bn;
@@ -1030,7 +1043,25 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
     hipStream_t st = static_cast<hipStream_t>(stream);
     ClPosEntry* tab = static_cast<ClPosEntry*>(ws);
     float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + p.tab_bytes);
-    {
+    bool build = true;
+    static const bool no_cache = getenv("DCV_CL_NO_POSTAB_CACHE") != nullptr;
+    if (!no_cache) {
+        ClTabKey key;
+        memset(&key, 0, sizeof(key));
+        DCV_HIP_CHECK(hipGetDevice(&key.dev));
+        const int32_t v[24] = {g->kd, g->kh, g->kw, g->sd, g->sh, g->sw, g->pd, g->ph, g->pw, D.n, D.d, D.h, D.w, G.d, G.h, G.w, (int32_t)G.sd, (int32_t)G.sh, (int32_t)G.sw, 0, 0, 0, 0, 0};
+        memcpy(key.v, v, sizeof(v));
+        key.w[0] = G.sn;
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        auto it = g_tabs.find(key);
+        if (it != g_tabs.end()) { tab = it->second; build = false; }
+        else {
+            ClPosEntry* dev_tab = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&dev_tab), p.tab_bytes) == hipSuccess) { g_tabs[key] = dev_tab; tab = dev_tab; }
+            else (void)hipGetLastError();      // no memory for a kept copy: this call builds into the workspace
+        }
+    }
+    if (build) {
         ClPosArgs a;
         memset(&a, 0, sizeof(a));
         a.tab = tab; a.M = (int)p.M; a.T = p.T; a.KH = g->kh; a.KW = g->kw;
@@ -1040,6 +1071,8 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
         a.g_sn = G.sn; a.g_sd = (int32_t)G.sd; a.g_sh = (int32_t)G.sh; a.g_sw = (int32_t)G.sw;
         hipLaunchKernelGGL(cl_postab_kernel, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, a);
         DCV_LAUNCH_CHECK();
+        // a kept table is read by later calls on OTHER streams (the discriminators' lanes): it must be complete before this call returns (once per layer)
+        if (tab != static_cast<ClPosEntry*>(ws)) DCV_HIP_CHECK(hipStreamSynchronize(st));
     }
     {
         ClWgradArgs a;

@@ -37,11 +37,13 @@ def pitch_of(c: int) -> int:
     return 8 if c <= 8 else (c + 31) // 32 * 32
 
 
-def cl_empty(shape, device, pitch: Optional[int] = None) -> torch.Tensor:
-    """(N, C, [D,] H, W) bf16 tensor in channels-last memory; padding channels (C < pitch) are zero."""
+def cl_empty(shape, device, pitch: Optional[int] = None, zero: bool = False) -> torch.Tensor:
+    """(N, C, [D,] H, W) bf16 tensor in channels-last memory.  Every kernel that produces a CL16 tensor writes whole 8-channel groups (zeros past C), and
+    every kernel that reads one stops at C rounded up to 8, so a fresh tensor needs no clearing; `zero=True` is for buffers whose channels are filled
+    piecewise (a concatenation whose total is not a multiple of 8)."""
     n, c, sp = shape[0], shape[1], tuple(shape[2:])
     p = pitch if pitch is not None else pitch_of(c)
-    make = torch.zeros if p != c else torch.empty
+    make = torch.zeros if zero else torch.empty
     store = make((n,) + sp + (p,), dtype=BF16, device=device)
     perm = (0, len(sp) + 1) + tuple(range(1, len(sp) + 1))
     return store.permute(*perm)[:, :c]
@@ -66,7 +68,7 @@ def as_cl(t: torch.Tensor) -> torch.Tensor:
         st = t.stride()
         if t.dim() < 3 or st[-1] % 8 == 0:
             return t
-    out = cl_empty(t.shape, t.device)
+    out = cl_empty(t.shape, t.device, zero=bool(t.shape[1] % 8))
     out.copy_(t)
     return out
 
@@ -297,7 +299,7 @@ class ConcatBuffer:
         self._join = _JoinSlices
         if ca % 8:
             raise N.NativeError("ConcatBuffer: the first member's channel count must be a multiple of 8 (16-byte aligned second slice)")
-        self.buf = cl_empty((n, ca + cb) + tuple(spatial), device)
+        self.buf = cl_empty((n, ca + cb) + tuple(spatial), device, zero=bool((ca + cb) % 8))
         self.first, self.second = self.buf[:, :ca], self.buf[:, ca:]
         self.slot = None
 

@@ -145,13 +145,13 @@ def test_bn_act_cl16(shape, act, drop):
     y_ref = F.leaky_relu(z, act[1]) if act[0] else z
     cot = r16(torch.randn(shape, generator=g))
     gr = torch.autograd.grad((y_ref * cot).sum(), [x, gamma, beta])
-    xc = ops_cl.cl_empty(shape, DEV); xc.copy_(x.detach().to(DEV)); xc.requires_grad_(True)
+    xc = ops_cl.cl_empty(shape, DEV, zero=True); xc.copy_(x.detach().to(DEV)); xc.requires_grad_(True)
     gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
     rmd, rvd = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
     nbt = torch.zeros((), dtype=torch.int64, device=DEV)
     md = mask.to(DEV).view(shape[0], Cn, 1, 1) if mask is not None else None
     y = ops_cl.bn_act(xc, gd, bd, rmd, rvd, True, ops.ACT_LEAKY if act[0] else ops.ACT_NONE, act[1], md, num_batches_tracked=nbt)
-    cc = ops_cl.cl_empty(shape, DEV); cc.copy_(cot.to(DEV))
+    cc = ops_cl.cl_empty(shape, DEV, zero=True); cc.copy_(cot.to(DEV))
     gh = torch.autograd.grad(y, [xc, gd, bd], cc)
     assert rel(y.float(), y_ref) < 5e-3 and rel(gh[0].float(), gr[0]) < 8e-3, (rel(y.float(), y_ref), rel(gh[0].float(), gr[0]))
     assert rel(gh[1], gr[1]) < 2e-3 and rel(gh[2], gr[2]) < 2e-3, (rel(gh[1], gr[1]), rel(gh[2], gr[2]))
@@ -164,7 +164,7 @@ def test_bn_act_cl16(shape, act, drop):
 def test_noise_and_activation_cl16():
     from dcvgan_amd import native, ops, ops_cl
     native.lib()
-    x = ops_cl.cl_empty((4, 64, 6, 8, 8), DEV); x.copy_(torch.randn(4, 64, 6, 8, 8, device=DEV))
+    x = ops_cl.cl_empty((4, 64, 6, 8, 8), DEV, zero=True); x.copy_(torch.randn(4, 64, 6, 8, 8, device=DEV))
     y = ops_cl.noise_add(x, 0.2, None, 1234, 7)
     d = (y.float() - x.float())
     assert abs(float(d.mean())) < 5e-3 and abs(float(d.std()) - 0.2) < 1e-2          # N(0, 0.2^2), up to bf16 rounding of the sum
