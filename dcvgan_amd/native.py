@@ -157,15 +157,15 @@ def set_precision(mode: str):
 
 
 def csrc_digest() -> str:
-    """sha256 over the kernel sources the library is built from (csrc/*.hip, *.h, build.sh, the public header).  Profiles committed under
-    profiles/ carry it, so a number measured on other kernels is never attached to this build (bench.py)."""
+    """sha256 over the sources of the fp32 kernels the headline benchmark runs (csrc/conv_mfma.hip, elementwise.hip, dcv_common.h, build.sh).
+    Profiles committed under profiles/ carry it, so a number measured on other kernels is never attached to this build (bench.py).  (The bf16
+    channels-last path's sources — conv_cl16.hip, cl_elementwise.hip — are separate translation units and not part of it.)"""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
-    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h", ".sh")))
-    for f in [os.path.join(src, f) for f in files] + [os.path.join(os.path.dirname(_HERE), "include", "dcvgan_hip.h")]:
-        h.update(os.path.basename(f).encode() + b"\0")
-        h.update(open(f, "rb").read())
+    for f in ("conv_mfma.hip", "elementwise.hip", "dcv_common.h", "build.sh"):
+        h.update(f.encode() + b"\0")
+        h.update(open(os.path.join(src, f), "rb").read())
     return h.hexdigest()
 
 
