@@ -7,7 +7,7 @@ import sys
 
 line = [l for l in open(sys.argv[2]) if l.startswith('{"metric"')][-1]
 b = json.loads(line)
-k = b["roofline"]["kernel"]
+k = b["roofline"].get("dominant_kernel") or b["roofline"]["kernel"]      # round 4 moved the kernel figures under roofline.dominant_kernel
 want = re.sub(r"\s*\(.*", "", k["kernel"]).replace(" ", "")          # gather_gemm_dma_kernel<2,2,1,4,false,true>
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if want in r["Kernel_Name"].replace(" ", "")]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
