@@ -197,7 +197,7 @@ class ColorVideoGenerator(nn.Module):
         skips = [self.inconv(ops_cl.from_f32(x), rng, out=bufs[0].second)]
         for k, blk in enumerate(self.down_blocks):
             dst = bufs[k + 1].second if k + 1 < 6 else bufs[6].first
-            skips.append(blk(skips[-1], rng, out=dst))
+            skips.append(blk(skips[-1], rng, out=dst, grad_slot=bufs[k].slot))      # skips[k] lives in bufs[k].second
         zc = ops_cl.from_f32(z, out=bufs[6].second)
         h = bufs[6].join(skips[6], zc)
         for i, blk in enumerate(self.up_blocks):

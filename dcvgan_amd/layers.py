@@ -84,7 +84,7 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             # bf16 channels-last data path: the same grouping (conv [+ activation] in one launch), ops_cl's kernels
             fused = _act_of(nxt) if nxt is not None else None
             last = i + (2 if fused is not None else 1) >= n
-            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None)
+            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None, grad_slot=grad_slot if i == 0 else None)
             i += 2 if fused is not None else 1
         elif isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None

@@ -201,8 +201,9 @@ def _packed(w: torch.Tensor, which: int, g: ConvGeom, xd, yd, key_dims):
 
 class _ConvCl(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, grad_slot=None):
         _req(x, "conv input"); N._require(w, "conv weight")
+        ctx.grad_slot = grad_slot
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
         shape = _out_shape(g, x)
@@ -228,11 +229,20 @@ class _ConvCl(Function):
         xd, dyd = dims5(x), dims5(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = cl_empty(x.shape, x.device)
+            # x is a U-Net skip tensor whose other consumer (the concatenation) has already delivered its gradient slice: add this data gradient into that
+            # slice in the GEMM epilogue and hand autograd nothing to sum (ops.GradSlot, as on the fp32 path)
+            slot = ctx.grad_slot
+            into = slot.take(x) if slot is not None else None
+            if into is not None and (into.dtype != BF16 or into.stride() != x.stride()):
+                slot.g, into = into, None
+            dx = into if into is not None else cl_empty(x.shape, x.device)
             dxd = dims5(dx)
             pk = _packed(w, 1, g, dxd, dyd, tuple(x.shape))
             wsp, wsn = _ws("clconv", L.dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1), x.device)
-            check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 0, wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_data")
+            check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), int(into is not None), wsp, wsn, stream_ptr()),
+                  "dcv_cl_conv_backward_data")
+            if into is not None:
+                dx = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
             need = L.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd))
@@ -240,12 +250,13 @@ class _ConvCl(Function):
                 raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + L.dcv_last_error().decode())
             wsp, wsn = _ws("clconv", need, x.device)
             check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None):
-    """y = act(conv(x, w)) on CL16 tensors; fp32 weights in torch layout; `out`: destination view (a channel slice of a concat buffer)."""
-    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out))
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, grad_slot=None):
+    """y = act(conv(x, w)) on CL16 tensors; fp32 weights in torch layout; `out`: destination view (a channel slice of a concat buffer);
+    `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection)."""
+    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out), grad_slot)
 
 
 # --------------------------------------------------------------------------- #
@@ -301,7 +312,8 @@ class ConcatBuffer:
             raise N.NativeError("ConcatBuffer: the first member's channel count must be a multiple of 8 (16-byte aligned second slice)")
         self.buf = cl_empty((n, ca + cb) + tuple(spatial), device, zero=bool((ca + cb) % 8))
         self.first, self.second = self.buf[:, :ca], self.buf[:, ca:]
-        self.slot = None
+        from .ops import GradSlot, _SKIP_ACCUMULATE
+        self.slot = GradSlot() if _SKIP_ACCUMULATE else None
 
     def join(self, a, b):
-        return self._join.apply(a, b, _Out(self.buf), None)
+        return self._join.apply(a, b, _Out(self.buf), self.slot)
