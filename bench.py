@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--minimal", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--no-minimal", action="store_true", help="skip the secondary `minimal_schedule` key (the schedule with the dead D-phase generator backward elided, "
                                                               "timed AFTER the headline region) — profile runs use this so that the trace holds the as-written schedule only")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary_precisions` key: short runs of the 16-bit paths (bf16 channels-last data path on "
+                                                                "surreal-depth1 — the config BASELINE names for bf16 — and on the headline config; fp32-on-bf16 on the headline config), timed AFTER everything else")
     ap.add_argument("--cpus", type=int, default=0, help="pin this rank to K host CPUs (host-headroom probe: 8 ranks on a 16-CPU share have 2 each)")
     return ap.parse_args()
 
@@ -425,6 +427,57 @@ def main():
                       "without_prefetcher": {"note": "the batch copied with .to(device, non_blocking=True) on the compute stream at the top of the iteration instead",
                                              "ms_per_step": dt4 / a.steps * 1e3, "slower_than_headline_pct": (dt4 / dt - 1.0) * 100.0}}
 
+    # secondary, clearly labelled: the 16-bit paths, each on freshly built models of its config, timed after everything above
+    secondary = None
+    if not a.no_secondary and a.precision == "fp32" and a.config == "isogd-depth" and not a.batch:
+        from dcvgan_amd import ops_cl
+        secondary = {}
+        legs = (("bf16cl", "surreal-depth1"), ("bf16cl", "isogd-depth"), ("f32x6", "isogd-depth"))
+        for prec, cname in legs:
+            c2 = CONFIGS[cname]
+            try:
+                if prec == "bf16cl":
+                    ops_cl.enable(True)
+                else:
+                    native.set_precision(prec)
+                torch.manual_seed(c2.seed)
+                m2 = trainer.build_models(c2, dev)
+                for m in m2.values():
+                    optim.broadcast_module(m)
+                torch.manual_seed(c2.seed + rank)
+                o2 = trainer.build_optimizers(c2, m2, data_parallel=world > 1)
+                r2 = trainer.StepRunner(c2, m2, o2, trainer.build_loss(c2), sync_losses=False)
+                g2 = torch.Generator().manual_seed(c2.seed + rank)
+                lo2, hi2 = (-0.5, 0.5) if c2.channel == 2 else (-1.0, 1.0)
+                xc2 = (torch.rand(c2.batchsize, 3, c2.video_length, 64, 64, generator=g2) * 2 - 1).to(dev)
+                xg2 = (torch.rand(c2.batchsize, c2.channel, c2.video_length, 64, 64, generator=g2) * (hi2 - lo2) + lo2).to(dev)
+                for i in range(3):
+                    out2 = r2.step(xc2, xg2, i)
+                ns = max(4, min(a.steps, 10))
+                sync()
+                t0 = time.perf_counter()
+                for i in range(ns):
+                    out2 = r2.step(xc2, xg2, (3 + i) % c2.video_length)
+                sync()
+                d2 = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([d2], device=dev, dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    d2 = t.item()
+                l2 = {k: float(v) for k, v in out2.items()}
+                assert all(x == x and abs(x) < 1e4 for x in l2.values()), l2
+                pk2 = PEAK_BF16_MFMA_TFLOPS if prec == "bf16cl" else PEAK_BF16_MFMA_TFLOPS / 6.0
+                f2 = flops_per_video_iteration(c2)
+                secondary[f"{prec}:{cname}"] = {"value": c2.batchsize * world / (d2 / ns), "unit": "videos/s", "ms_per_step": d2 / ns * 1e3, "steps": ns, "per_gpu_batch": c2.batchsize,
+                                                "frac_of_its_mfma_peak": f2 * (c2.batchsize / (d2 / ns)) / 1e12 / pk2, "peak_tflops": pk2, "losses_last_step": l2}
+                del m2, o2, r2, xc2, xg2
+            finally:
+                ops_cl.enable(False)
+                native.set_precision("fp32")
+            torch.cuda.empty_cache()
+        secondary["note"] = ("NOT the headline: bf16cl = bf16 channels-last data path (activations / gradients bf16 in HBM, fp32 masters, statistics, accumulation, optimiser; "
+                             "tolerance tests tests/test_cl16_gpu.py); f32x6 = fp32 emulated on the bf16 matrix pipe in the forward / data-gradient GEMMs (experimental); DESIGN §8")
+
     if rank == 0:
         per_step = dt / a.steps
         vps = B * world / per_step
@@ -461,6 +514,7 @@ def main():
             "cpu_baseline": cpu,
             "minimal_schedule": minimal,
             "as_trainer": as_trainer,
+            "secondary_precisions": secondary,
             "losses_last_step": losses,
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
         }

@@ -13,7 +13,7 @@ hipcc $F -c dcvgan_amd/csrc/conv_mfma.hip -o $O/conv_mfma.o 2> $O/conv.log &
 hipcc $F -c dcvgan_amd/csrc/elementwise.hip -o $O/elementwise.o 2> $O/ew.log &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/alt.so $O/conv_mfma.o $O/elementwise.o || { tail $O/conv.log; exit 1; }
-bench() { timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-minimal --no-as-trainer --steps 12 --warmup 3 "$@" 2>/dev/null | python3 -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])"; }
+bench() { timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-minimal --no-as-trainer --no-secondary --steps 12 --warmup 3 "$@" 2>/dev/null | python3 -c "import sys,json; print('%.2f' % json.loads(sys.stdin.read())['ms_per_step'])"; }
 if [ -n "$DCV_AB_TESTS" ]; then cp /tmp/alt.so $SO; timeout -k 10 900 python3 -m pytest $DCV_AB_TESTS -x -q -m gpu 2>&1 | tail -n 3; fi
 for i in $(seq 1 $P); do
 cp /tmp/base.so $SO; a=$(bench "$@") || exit 1

@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_step
-CMD="python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-minimal --no-as-trainer"
+CMD="python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-minimal --no-as-trainer --no-secondary"
 run() { rm -rf /tmp/pmc_$1; timeout -k 10 400 rocprofv3 --pmc $2 -d /tmp/pmc_$1 -o p --output-format csv -- $CMD > gpurun_out/pmc_step/$1.log 2>&1 || { tail -3 gpurun_out/pmc_step/$1.log; exit 1; }; }
 run FETCH "FETCH_SIZE" && run WRITE "WRITE_SIZE" && \
 run SQ "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" || exit 1

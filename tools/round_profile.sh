@@ -7,13 +7,13 @@ export TMPDIR=/tmp
 O=gpurun_out/round; rm -rf $O; mkdir -p $O; rm -rf /tmp/rp /tmp/pd_*
 timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err || { tail -3 $O/bench.err; exit 1; }
 echo "bench done"; cut -c1-200 $O/bench.json
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/rp -o r --output-format csv -- python3 bench.py --no-cpu-baseline --no-minimal --no-as-trainer --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1 || { tail -3 $O/bench_under_rocprof.log; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/rp -o r --output-format csv -- python3 bench.py --no-cpu-baseline --no-minimal --no-as-trainer --no-secondary --steps 5 --warmup 2 > $O/bench_under_rocprof.log 2>&1 || { tail -3 $O/bench_under_rocprof.log; exit 1; }
 find /tmp/rp -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_lanes.csv \;
 find /tmp/rp -name "*kernel_trace.csv" -exec cp {} /tmp/rp/trace.csv \;
 # the same command with the discriminators' side streams off: kernels run one at a time, so the per-kernel durations add up to the step
 # (with the lanes on, co-running kernels each report the whole overlapped interval)
 rm -rf /tmp/rs
-DCV_NO_SIDE_STREAMS=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/rs -o r --output-format csv -- python3 bench.py --no-cpu-baseline --no-minimal --no-as-trainer --steps 5 --warmup 2 > $O/bench_under_rocprof_serial.log 2>&1 || { tail -3 $O/bench_under_rocprof_serial.log; exit 1; }
+DCV_NO_SIDE_STREAMS=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/rs -o r --output-format csv -- python3 bench.py --no-cpu-baseline --no-minimal --no-as-trainer --no-secondary --steps 5 --warmup 2 > $O/bench_under_rocprof_serial.log 2>&1 || { tail -3 $O/bench_under_rocprof_serial.log; exit 1; }
 find /tmp/rs -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 python3 tools/dominant_from_trace.py /tmp/rp/trace.csv $O/bench_under_rocprof.log > $O/dominant_kernel_trace.json || exit 1
 echo "trace done"; cat $O/dominant_kernel_trace.json
@@ -24,7 +24,7 @@ echo "pmc dominant done"; cat $O/dominant_kernel_pmc.json
 bash tools/pmc_step.sh > $O/pmc_step.log 2>&1 || { tail -3 $O/pmc_step.log; exit 1; }
 cp gpurun_out/pmc_step/summary.json $O/pmc_step_summary.json; tail -n 10 $O/pmc_step.log
 # round 3: one --kernel-trace --stats summary each for the two B = 100 configs and for the 32 x 128 x 128 discriminator stress shape (program directly after --)
-for c in surreal-depth1 isogd-flow; do rm -rf /tmp/rc_$c; DCV_NO_SIDE_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/rc_$c -o r --output-format csv -- python3 bench.py --config $c --no-cpu-baseline --no-minimal --no-as-trainer --steps 3 --warmup 1 > $O/bench_under_rocprof_$c.log 2>&1 || { tail -3 $O/bench_under_rocprof_$c.log; exit 1; }
+for c in surreal-depth1 isogd-flow; do rm -rf /tmp/rc_$c; DCV_NO_SIDE_STREAMS=1 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/rc_$c -o r --output-format csv -- python3 bench.py --config $c --no-cpu-baseline --no-minimal --no-as-trainer --no-secondary --steps 3 --warmup 1 > $O/bench_under_rocprof_$c.log 2>&1 || { tail -3 $O/bench_under_rocprof_$c.log; exit 1; }
 find /tmp/rc_$c -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$c.csv \; ; done
 timeout -k 10 200 python3 tools/stress_d.py 4 > $O/stress_d_b4.txt 2>&1 || { tail -3 $O/stress_d_b4.txt; exit 1; }; tail -n 1 $O/stress_d_b4.txt
 rm -rf /tmp/rstress; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/rstress -o r --output-format csv -- python3 tools/stress_d.py 4 > $O/stress_d_under_rocprof.log 2>&1 || { tail -3 $O/stress_d_under_rocprof.log; exit 1; }
