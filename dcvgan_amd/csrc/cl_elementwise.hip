@@ -177,9 +177,37 @@ struct ClBnArgs {
 };
 template <int NV>
 __device__ __forceinline__ void cl_bn_block_out(double (&s)[8][NV], const ClBnArgs& a, int g, int p, int PB, double* red) {
-    // red[PB][G*8][NV] would not fit for large PB * C: reduce over p in rounds of LDS [G * 8][NV] per p-slot pair via sequential accumulation
-    // fixed order: thread p = 0 of each group sums the PB contributions p = 0 .. PB - 1 from LDS
-    const int C8 = a.G * 8;
+    // combine the block's PB pixel slots per channel, in a fixed order, and write partial[block][C][NV]
+    if ((a.G & (a.G - 1)) == 0 && a.G <= 64) {
+        // G | 64: thread p * G + g sits on lane (p * G + g) % 64, so the slots of one group within a wave are G lanes apart: xor tree over the lane bits
+        // above log2(G), then the four waves meet in LDS (red: [4][G * 8][NV])
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                for (int o = a.G; o < 64; o <<= 1) s[e][v] += __shfl_xor(s[e][v], o, 64);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane < a.G)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) red[((wave * a.G + lane) * 8 + e) * NV + v] = s[e][v];
+        __syncthreads();
+        if ((int)threadIdx.x < a.G)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = g * 8 + e;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    double t = 0.0;
+                    for (int w = 0; w < 4; ++w) t += red[((w * a.G + g) * 8 + e) * NV + v];
+                    if (c < a.C) a.partial[((int64_t)blockIdx.x * a.C + c) * NV + v] = t;
+                }
+            }
+        return;
+    }
+    // other group counts (12, 24, 48, 96: ngf = 96): slot p = 0 of each group adds the slots p = 1 .. PB - 1 one after the other through LDS (red: [G * 8][NV])
     for (int q = 1; q < PB; ++q) {
         __syncthreads();
         if (p == q)
@@ -194,7 +222,6 @@ __device__ __forceinline__ void cl_bn_block_out(double (&s)[8][NV], const ClBnAr
 #pragma unroll
                 for (int v = 0; v < NV; ++v) s[e][v] += red[(g * 8 + e) * NV + v];
     }
-    (void)C8;
     if (p == 0)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -216,13 +243,25 @@ __global__ __launch_bounds__(256) void cl_bn_stats_kernel(const ClBnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { f1[e] = 0.f; f2[e] = 0.f; }
         int run = 0;
-        for (int64_t q = (int64_t)blockIdx.x * PB + p; q < a.P; q += (int64_t)gridDim.x * PB) {
-            const uint32_t n = fdiv((uint32_t)q, a.div_pix), pix = (uint32_t)q - n * a.div_pix.div;
-            float v[8];
-            cl_unpack(cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8), v);
+        const int64_t stride = (int64_t)gridDim.x * PB;
+        for (int64_t q = (int64_t)blockIdx.x * PB + p; q < a.P; q += 4 * stride) {
+            u32x4 w[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { f1[e] += v[e]; f2[e] += v[e] * v[e]; }
-            if (++run == 64) {
+            for (int u = 0; u < 4; ++u) {      // four independent 16-byte loads in flight per thread
+                const int64_t qq = q + u * stride;
+                const bool ok = qq < a.P;
+                const uint32_t n = fdiv((uint32_t)(ok ? qq : q), a.div_pix), pix = (uint32_t)(ok ? qq : q) - n * a.div_pix.div;
+                w[u] = cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8);
+                if (!ok) w[u] = u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                cl_unpack(w[u], v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { f1[e] += v[e]; f2[e] += v[e] * v[e]; }
+            }
+            if (++run == 16) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e][0] += f1[e]; s[e][1] += f2[e]; f1[e] = 0.f; f2[e] = 0.f; }
                 run = 0;
@@ -330,22 +369,36 @@ __global__ __launch_bounds__(256) void cl_bn_bwd_reduce_kernel(const ClBnArgs a)
             f1[e] = 0.f; f2[e] = 0.f; sc[e] = a.scale[c]; sh[e] = a.shift[c]; mu[e] = a.c1[c]; is[e] = a.c2[c];
         }
         int run = 0;
-        for (int64_t q = (int64_t)blockIdx.x * PB + p; q < a.P; q += (int64_t)gridDim.x * PB) {
-            const uint32_t n = fdiv((uint32_t)q, a.div_pix), pix = (uint32_t)q - n * a.div_pix.div;
-            float x[8], d[8];
-            cl_unpack(cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8), x);
-            cl_unpack(cl_ld(a.dy + (int64_t)n * a.dyv.sn + (int64_t)pix * a.dyv.pitch + g * 8), d);
+        const int64_t stride = (int64_t)gridDim.x * PB;
+        for (int64_t q = (int64_t)blockIdx.x * PB + p; q < a.P; q += 2 * stride) {
+            u32x4 wx[2], wd[2];
+            uint32_t nn[2];
+            bool okk[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = g * 8 + e;
-                float mk = 1.f;
-                if (a.mask && c < a.C) mk = a.mask[(int64_t)n * a.C + c];
-                const float z = mk * (x[e] * sc[e] + sh[e]);
-                float dz = d[e] * mk;
-                if (a.act == DCV_ACT_LEAKY) dz *= z > 0.f ? 1.f : a.slope;
-                f1[e] += dz; f2[e] += dz * (x[e] - mu[e]) * is[e];
+            for (int u = 0; u < 2; ++u) {      // two pixels = four independent 16-byte loads in flight per thread
+                const int64_t qq = q + u * stride;
+                okk[u] = qq < a.P;
+                const uint32_t n = fdiv((uint32_t)(okk[u] ? qq : q), a.div_pix), pix = (uint32_t)(okk[u] ? qq : q) - n * a.div_pix.div;
+                nn[u] = n;
+                wx[u] = cl_ld(a.x + (int64_t)n * a.xv.sn + (int64_t)pix * a.xv.pitch + g * 8);
+                wd[u] = cl_ld(a.dy + (int64_t)n * a.dyv.sn + (int64_t)pix * a.dyv.pitch + g * 8);
             }
-            if (++run == 64) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float x[8], d[8];
+                cl_unpack(wx[u], x); cl_unpack(wd[u], d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = g * 8 + e;
+                    float mk = 1.f;
+                    if (a.mask && c < a.C) mk = a.mask[(int64_t)nn[u] * a.C + c];
+                    const float z = mk * (x[e] * sc[e] + sh[e]);
+                    float dz = okk[u] ? d[e] * mk : 0.f;
+                    if (a.act == DCV_ACT_LEAKY) dz *= z > 0.f ? 1.f : a.slope;
+                    f1[e] += dz; f2[e] += dz * (x[e] - mu[e]) * is[e];
+                }
+            }
+            if (++run == 32) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e][0] += f1[e]; s[e][1] += f2[e]; f1[e] = 0.f; f2[e] = 0.f; }
                 run = 0;
@@ -533,7 +586,7 @@ int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv
     a.scale = coef; a.shift = coef + a.C;
     const int cb = (a.C + 63) / 64;
     if (training) {
-        hipLaunchKernelGGL(cl_bn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)a.C * 2 * sizeof(double), st, a);
+        hipLaunchKernelGGL(cl_bn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * 2 * sizeof(double), st, a);
         DCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(cl_bn_finalize_kernel, dim3((unsigned)a.C), dim3(256), 0, st, partial, blocks, a.C, (double)a.P, eps, momentum, running_mean, running_var,
                            num_batches_tracked, save_mean, save_invstd);
@@ -573,7 +626,7 @@ int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, 
                        coef, coef + a.C, (float*)nullptr, (float*)nullptr);
     DCV_LAUNCH_CHECK();
     a.c1 = save_mean; a.c2 = save_invstd;
-    hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)a.C * 2 * sizeof(double), st, a);
+    hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * 2 * sizeof(double), st, a);
     DCV_LAUNCH_CHECK();
     float* k1 = coef + 2 * a.C; float* k2 = coef + 3 * a.C; float* k3 = coef + 4 * a.C;
     hipLaunchKernelGGL(cl_bn_bwd_finalize_kernel, dim3((unsigned)a.C), dim3(256), 0, st, partial, blocks, a.C, (double)a.P, training, gamma, save_mean, save_invstd,
