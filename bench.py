@@ -393,7 +393,7 @@ def main():
     # .cpu().item() where trainer.py:326-328,363 read them, and every iteration starts from a fresh pinned host batch .to(device)
     # (trainer.py:293-297; the DataLoader there pins memory, train.py:101-109).  The headline above stays the HBM-resident, sync-free figure.
     as_trainer = None
-    if not a.no_as_trainer:
+    if not a.no_as_trainer and world == 1:      # (N = 1 only: a secondary key must never be able to stall or fail a multi-rank headline run)
         import itertools
         from dcvgan_amd.dataprep import DevicePrefetcher
         pin = [(xc.cpu().pin_memory(), xg.cpu().pin_memory()) for _ in range(2)]      # a loader's double buffer (DataLoader(pin_memory=True), train.py:101-109)
@@ -415,21 +415,24 @@ def main():
             at.step(None, None, 0)
             d, _ = timed(at, a.steps, 1)
             return d
-        dt3 = leg(True)
-        dt4 = leg(False)
-        as_trainer = {"note": "NOT the headline: sync_losses=True (four .cpu().item() host reads per iteration where trainer.py:326-328,363 has them; the loss objects "
-                              "carry an event-guarded pinned host copy, dcvgan_amd.loss.HostMirroredLoss, so a read waits for the loss kernels, not for the "
-                              "backward + Adam enqueued behind them) + a fresh pinned host batch copied to the device every iteration (trainer.py:293-297) "
-                              "through dcvgan_amd.dataprep.DevicePrefetcher (side stream, one batch ahead)",
-                      "value": B * world / (dt3 / a.steps), "unit": "videos/s", "ms_per_step": dt3 / a.steps * 1e3,
-                      "slower_than_headline_pct": (dt3 / dt - 1.0) * 100.0,
-                      "h2d_mb_per_step": (xc.numel() + xg.numel()) * 4 / 1e6,
-                      "without_prefetcher": {"note": "the batch copied with .to(device, non_blocking=True) on the compute stream at the top of the iteration instead",
-                                             "ms_per_step": dt4 / a.steps * 1e3, "slower_than_headline_pct": (dt4 / dt - 1.0) * 100.0}}
+        try:
+            dt3 = leg(True)
+            dt4 = leg(False)
+            as_trainer = {"note": "NOT the headline: sync_losses=True (four .cpu().item() host reads per iteration where trainer.py:326-328,363 has them; the loss objects "
+                                  "carry an event-guarded pinned host copy, dcvgan_amd.loss.HostMirroredLoss, so a read waits for the loss kernels, not for the "
+                                  "backward + Adam enqueued behind them) + a fresh pinned host batch copied to the device every iteration (trainer.py:293-297) "
+                                  "through dcvgan_amd.dataprep.DevicePrefetcher (side stream, one batch ahead)",
+                          "value": B * world / (dt3 / a.steps), "unit": "videos/s", "ms_per_step": dt3 / a.steps * 1e3,
+                          "slower_than_headline_pct": (dt3 / dt - 1.0) * 100.0,
+                          "h2d_mb_per_step": (xc.numel() + xg.numel()) * 4 / 1e6,
+                          "without_prefetcher": {"note": "the batch copied with .to(device, non_blocking=True) on the compute stream at the top of the iteration instead",
+                                                 "ms_per_step": dt4 / a.steps * 1e3, "slower_than_headline_pct": (dt4 / dt - 1.0) * 100.0}}
+        except Exception as e:          # a secondary key: the headline line is still printed
+            as_trainer = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # secondary, clearly labelled: the 16-bit paths, each on freshly built models of its config, timed after everything above
     secondary = None
-    if not a.no_secondary and a.precision == "fp32" and a.config == "isogd-depth" and not a.batch:
+    if not a.no_secondary and world == 1 and a.precision == "fp32" and a.config == "isogd-depth" and not a.batch:
         from dcvgan_amd import ops_cl
         secondary = {}
         legs = (("bf16cl", "surreal-depth1"), ("bf16cl", "isogd-depth"), ("f32x6", "isogd-depth"))
@@ -471,6 +474,8 @@ def main():
                 secondary[f"{prec}:{cname}"] = {"value": c2.batchsize * world / (d2 / ns), "unit": "videos/s", "ms_per_step": d2 / ns * 1e3, "steps": ns, "per_gpu_batch": c2.batchsize,
                                                 "frac_of_its_mfma_peak": f2 * (c2.batchsize / (d2 / ns)) / 1e12 / pk2, "peak_tflops": pk2, "losses_last_step": l2}
                 del m2, o2, r2, xc2, xg2
+            except Exception as e:      # a secondary leg may fail; the headline line is still printed
+                secondary[f"{prec}:{cname}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             finally:
                 ops_cl.enable(False)
                 native.set_precision("fp32")
