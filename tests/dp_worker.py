@@ -1,6 +1,6 @@
 """Child process of tests/test_dp_gpu.py: one data-parallel rank driving the REAL DCVGAN modules (width / 8) through
 trainer.StepRunner + optim.DataParallelAdam on cuda:0, gloo collectives (two ranks may share one card; RCCL refuses
-that).  Usage: python tests/dp_worker.py RANK WORLD PORT MODE OUT.json      MODE: "distinct" | "same" """
+that).  Usage: python tests/dp_worker.py RANK WORLD PORT MODE OUT.json      MODE: "distinct" | "same" | "same-cl16" (the bf16 channels-last data path) """
 import copy
 import json
 import os
@@ -17,8 +17,11 @@ def main():
     rank, world, port, mode, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = port
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from dcvgan_amd import optim, trainer
+    from dcvgan_amd import ops_cl, optim, trainer
     from dcvgan_amd.configs import CONFIGS
+    if mode.endswith("-cl16"):
+        ops_cl.enable(True)
+        mode = mode[:-5]
     from dcvgan_amd.rng import PhiloxRng
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)

@@ -329,3 +329,31 @@ def test_stress_shape_32x128x128_cl16():
     cosn = lambda a, b: float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()))
     assert cosn(got[2], ref[2]) > 0.98 and cosn(got[3], ref[3]) > 0.98, (cosn(got[2], ref[2]), cosn(got[3], ref[3]))
     assert rel(got[4], ref[4]) < 0.15, rel(got[4], ref[4])
+
+
+def test_iteration_cl16_is_bitwise_reproducible():
+    """Two runs of the same two iterations from the same seeds on the CL16 path give bit-identical losses and parameters: no atomics, every reduction
+    (BatchNorm partials, weight-gradient slabs) in a fixed order — also with the discriminators on their own streams."""
+    from dcvgan_amd import native, ops_cl, trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    native.lib()
+    cfg = CONFIGS["isogd-flow"].scaled(batchsize=2, width_div=2)
+    g = torch.Generator().manual_seed(1)
+    xc = (torch.rand(2, 3, 16, 64, 64, generator=g) * 2 - 1).to(DEV); xg = (torch.rand(2, 2, 16, 64, 64, generator=g) - 0.5).to(DEV)
+    res = []
+    ops_cl.enable(True)
+    try:
+        for _ in range(2):
+            torch.manual_seed(9)
+            models = trainer.build_models(cfg, DEV)
+            r = PhiloxRng(5)
+            for m in models.values():
+                m._rng = r
+            runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
+            outs = [runner.step(xc, xg, 3), runner.step(xc, xg, 8)]
+            res.append((outs, torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).clone()))
+    finally:
+        ops_cl.enable(False)
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])

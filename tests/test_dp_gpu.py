@@ -40,6 +40,13 @@ def test_two_ranks_same_data_equal_one_process(tmp_path):
         assert r["replicas_identical"] and r["equals_single_process"] and r["moved"], r
 
 
+def test_two_ranks_same_data_equal_one_process_cl16(tmp_path):
+    """The same exactness statement on the bf16 channels-last data path: its weight gradients are fp32 and every reduction in it has a fixed order, so two ranks
+    on the same data reproduce the single-process run bit for bit (data parallelism needs nothing from that path but fp32 gradients in the buckets)."""
+    for r in _run("same-cl16", tmp_path):
+        assert r["replicas_identical"] and r["equals_single_process"] and r["moved"], r
+
+
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks itself (fresh children, before any HIP call)
     and relays rank 0's single JSON line.  Two ranks share the card here, hence gloo (RCCL refuses two ranks on one device)."""
