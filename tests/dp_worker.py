@@ -19,13 +19,15 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dcvgan_amd import ops_cl, optim, trainer
     from dcvgan_amd.configs import CONFIGS
+    wdiv = 8
     if mode.endswith("-cl16"):
         ops_cl.enable(True)
         mode = mode[:-5]
+        wdiv = 4          # (that path concatenates 8-channel-aligned slices: the stems' ndf / 2 channels must be a multiple of 8)
     from dcvgan_amd.rng import PhiloxRng
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    cfg = CONFIGS["isogd-depth"].scaled(batchsize=2, width_div=8)
+    cfg = CONFIGS["isogd-depth"].scaled(batchsize=2, width_div=wdiv)
     torch.manual_seed(cfg.seed + 17 * rank)                    # deliberately different replicas ...
     models = trainer.build_models(cfg, dev)
     for m in models.values():
