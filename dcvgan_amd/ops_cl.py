@@ -15,8 +15,8 @@ import torch
 from torch.autograd import Function
 
 from . import native as N
-from .native import ACT_LEAKY, ACT_NONE, ACT_TANH, ConvGeom, check, dims5, lib, ptr, stream_ptr
-from .ops import _Opaque, _Out, _out_shape, _ws
+from .native import ACT_LEAKY, ACT_NONE, ConvGeom, check, dims5, lib, ptr, stream_ptr
+from .ops import _Out, _out_shape, _ws
 
 BF16 = torch.bfloat16
 _ENABLED = [False]
