@@ -171,6 +171,7 @@ struct ClBnArgs {
     const float* scale; const float* shift;      // y = act(mask * (x * scale + shift))
     const float* mask;               // N * C or null
     const float* c1; const float* c2; const float* c3;   // backward: dx = c1 * dz - c2 * xhat' ... (see cl_bn_bwd_apply)
+    const float* gamma; const float* beta; const float* mean; const float* invstd;   // backward kernels form scale / shift themselves (one launch less)
     double* partial;                 // [blocks][C][NV]
     int32_t act; float slope;
     int32_t pb, pad;                 // pixels per block iteration
@@ -291,7 +292,8 @@ __device__ __forceinline__ double cl_partial_sum(const double* __restrict__ part
 // mean / invstd / running statistics from the partials (training) — one 256-thread workgroup per channel, fp64, fixed order
 __global__ __launch_bounds__(256) void cl_bn_finalize_kernel(const double* __restrict__ partial, int nblocks, int C, double count, float eps, float momentum,
                                                              float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
-                                                             float* __restrict__ mean, float* __restrict__ invstd) {
+                                                             float* __restrict__ mean, float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ double red[256];
     const int c = blockIdx.x;
     const double s1 = cl_partial_sum(partial, nblocks, C, c, 0, 2, red), s2 = cl_partial_sum(partial, nblocks, C, c, 1, 2, red);
@@ -301,7 +303,10 @@ __global__ __launch_bounds__(256) void cl_bn_finalize_kernel(const double* __res
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    invstd[c] = is;
+    scale[c] = gamma[c] * is;                       // the apply pass's coefficients: y = act(mask * (x * scale + shift))
+    shift[c] = beta[c] - (float)m * gamma[c] * is;
     if (rm) {
         const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
         rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * m);
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) void cl_bn_bwd_reduce_kernel(const ClBnArgs a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = min(g * 8 + e, a.C - 1);
-            f1[e] = 0.f; f2[e] = 0.f; sc[e] = a.scale[c]; sh[e] = a.shift[c]; mu[e] = a.c1[c]; is[e] = a.c2[c];
+            f1[e] = 0.f; f2[e] = 0.f; mu[e] = a.mean[c]; is[e] = a.invstd[c]; sc[e] = a.gamma[c] * is[e]; sh[e] = a.beta[c] - mu[e] * sc[e];
         }
         int run = 0;
         const int64_t stride = (int64_t)gridDim.x * PB;
@@ -435,7 +440,11 @@ __global__ __launch_bounds__(256) void cl_bn_bwd_apply_kernel(const ClBnArgs a, 
     if (p >= PB) return;
     float sc[8], sh[8], k1[8], k2[8], k3[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const int c = g * 8 + e; sc[e] = a.scale[c]; sh[e] = a.shift[c]; k1[e] = a.c1[c]; k2[e] = a.c2[c]; k3[e] = a.c3[c]; }
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        sc[e] = a.gamma[c] * a.invstd[c]; sh[e] = a.beta[c] - a.mean[c] * sc[e];
+        k1[e] = a.c1[c]; k2[e] = a.c2[c]; k3[e] = a.c3[c];
+    }
     const bool leaky = a.act == DCV_ACT_LEAKY;
     const float slope = a.slope;
     const int64_t stride = (int64_t)gridDim.x * PB;
@@ -589,10 +598,7 @@ int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv
         hipLaunchKernelGGL(cl_bn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * 2 * sizeof(double), st, a);
         DCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(cl_bn_finalize_kernel, dim3((unsigned)a.C), dim3(256), 0, st, partial, blocks, a.C, (double)a.P, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, save_mean, save_invstd);
-        DCV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(cl_bn_coeff_kernel, dim3((unsigned)cb), dim3(64), 0, st, a.C, gamma, beta, save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, eps,
-                           coef, coef + a.C, save_mean, save_invstd);
+                           num_batches_tracked, save_mean, save_invstd, gamma, beta, coef, coef + a.C);
     } else {
         if (!running_mean || !running_var) return fail(DCV_EINVAL, "cl_bn_act_forward: eval mode needs running statistics");
         hipLaunchKernelGGL(cl_bn_coeff_kernel, dim3((unsigned)cb), dim3(64), 0, st, a.C, gamma, beta, (const float*)nullptr, (const float*)nullptr, running_mean, running_var, eps,
@@ -622,9 +628,7 @@ int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, 
     a.x = static_cast<const __bf16*>(x); a.dy = static_cast<const __bf16*>(dy); a.y = static_cast<__bf16*>(dx); a.partial = partial; a.mask = mask; a.act = act; a.slope = slope;
     a.scale = coef; a.shift = coef + a.C;
     const int cb = (a.C + 63) / 64;
-    hipLaunchKernelGGL(cl_bn_coeff_kernel, dim3((unsigned)cb), dim3(64), 0, st, a.C, gamma, beta, save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, 0.f,
-                       coef, coef + a.C, (float*)nullptr, (float*)nullptr);
-    DCV_LAUNCH_CHECK();
+    a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.invstd = save_invstd;
     a.c1 = save_mean; a.c2 = save_invstd;
     hipLaunchKernelGGL(cl_bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * 2 * sizeof(double), st, a);
     DCV_LAUNCH_CHECK();
