@@ -29,7 +29,7 @@ xc = (torch.rand(B, 3, 16, 64, 64, generator=g) * 2 - 1).to(dev); xg = (torch.ra
 marks = []
 for i in range(N):
     out = runner.step(xc, xg, i % 16)
-    if i in (5, 20, N // 2, N - 1):
+    if i in (5, 20, N // 2, N - 1) or (os.environ.get('SOAK_VERBOSE') and i % 20 in (0, 1)):
         torch.cuda.synchronize()
         marks.append((i, torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e3,
                       {k: round(float(v), 4) for k, v in out.items()}))
