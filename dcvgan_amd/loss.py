@@ -39,11 +39,14 @@ class HostMirroredLoss:
             done = torch.cuda.Event()
             done.record(side)
         src.record_stream(side)
-        plain_cpu = t.cpu
+        # the closure must not own `t` (t.__dict__ -> closure -> t would be a reference cycle: the loss tensor, and with it the whole autograd graph of a phase
+        # whose backward was gated off, would live until Python's cycle collector happens to run — measured as GB-sized steps in device memory)
+        import weakref
+        wt = weakref.ref(t)
 
         def cpu(*args, **kwargs):
             if args or kwargs:
-                return plain_cpu(*args, **kwargs)
+                return torch.Tensor.cpu(wt(), *args, **kwargs)
             done.synchronize()
             return host.clone()
         t.cpu = cpu          # instance attribute: shadows torch.Tensor.cpu for this object only
