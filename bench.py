@@ -304,7 +304,8 @@ def main():
         numa_cpus = gpu_numa_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         if numa_cpus:
             os.sched_setaffinity(0, set(numa_cpus))
-    torch.set_num_threads(max(1, host_threads() // max(1, world)))    # N ranks share the host's CPU quota
+    # N ranks share the host's CPU quota (a rank already pinned to its own CPU set uses that set)
+    torch.set_num_threads(max(1, len(numa_cpus)) if numa_cpus else max(1, host_threads() // max(1, world)))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     if a.all_ranks_on_device0:
         local = 0
