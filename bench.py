@@ -72,24 +72,19 @@ def parse():
 
 
 def gpu_numa_cpus(local_rank, local_world):
-    """CPUs of the NUMA node GPU `local_rank` hangs off, this rank's share of them.  AMD GPUs under /sys/class/drm (vendor 0x1002) in PCI
-    bus order — HIP's default enumeration order — filtered through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are plain index
-    lists.  None when anything is missing (containers often hide sysfs): the rank then keeps the affinity it was started with."""
-    import glob
+    """CPUs of the NUMA node GPU `local_rank` hangs off, this rank's share of them.  The node comes from the device's own PCI address
+    (torch's device properties -> /sys/bus/pci/devices/<address>/numa_node), so no enumeration order is assumed; ranks whose GPUs share a
+    node split its CPUs.  None when anything is missing (containers often hide sysfs; older torch has no PCI fields): the rank then keeps
+    the affinity it was started with.  Needs the device runtime, so it runs after torch.cuda.set_device."""
+    def node_of(i):
+        p = torch.cuda.get_device_properties(i)
+        addr = "%04x:%02x:%02x.0" % (int(getattr(p, "pci_domain_id")), int(getattr(p, "pci_bus_id")), int(getattr(p, "pci_device_id")))
+        return int(open(f"/sys/bus/pci/devices/{addr}/numa_node").read())
     try:
-        gpus = []
-        for d in glob.glob("/sys/class/drm/renderD*/device"):
-            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":
-                continue
-            gpus.append((os.path.basename(os.path.realpath(d)), int(open(os.path.join(d, "numa_node")).read())))
-        gpus.sort()
-        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
-            v = os.environ.get(var)
-            if v and all(x.strip().isdigit() for x in v.split(",")):
-                gpus = [gpus[int(x)] for x in v.split(",")]
-        if local_rank >= len(gpus):
+        n_dev = torch.cuda.device_count()
+        if local_rank >= n_dev:
             return None
-        node = gpus[local_rank][1]
+        node = node_of(local_rank)
         if node < 0:
             return None
         cpus = []
@@ -97,7 +92,7 @@ def gpu_numa_cpus(local_rank, local_world):
             lo, _, hi = part.partition("-")
             cpus += list(range(int(lo), int(hi or lo) + 1))
         cpus = sorted(set(cpus) & os.sched_getaffinity(0))
-        peers = [r for r in range(local_world) if r < len(gpus) and gpus[r][1] == node]      # ranks whose GPU shares this node split its CPUs
+        peers = [r for r in range(min(local_world, n_dev)) if r == local_rank or node_of(r) == node]
         if not cpus or local_rank not in peers:
             return None
         share = max(1, len(cpus) // len(peers))
@@ -298,19 +293,19 @@ def main():
     if a.cpus:
         mine = sorted(os.sched_getaffinity(0))
         os.sched_setaffinity(0, set(mine[(rank * a.cpus) % len(mine):][:a.cpus]) or set(mine[:a.cpus]))
-    elif world > 1 and not a.all_ranks_on_device0:
-        # every rank (spawned by us or by torch.distributed.run) enqueues ~900 launches per iteration from one Python thread: keep that thread
-        # and its allocator on the NUMA node its GPU hangs off (before HIP is initialised, so the runtime's own threads inherit the mask)
-        numa_cpus = gpu_numa_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-        if numa_cpus:
-            os.sched_setaffinity(0, set(numa_cpus))
-    # N ranks share the host's CPU quota (a rank already pinned to its own CPU set uses that set)
-    torch.set_num_threads(max(1, len(numa_cpus)) if numa_cpus else max(1, host_threads() // max(1, world)))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     if a.all_ranks_on_device0:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1 and not a.cpus and not a.all_ranks_on_device0:
+        # every rank (spawned by us or by torch.distributed.run) enqueues ~900 launches per iteration from one Python thread: keep that thread and
+        # its allocations on the NUMA node its GPU hangs off
+        numa_cpus = gpu_numa_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        if numa_cpus:
+            os.sched_setaffinity(0, set(numa_cpus))
+    # N ranks share the host's CPU quota (a rank pinned to its own CPU set uses that set)
+    torch.set_num_threads(max(1, len(numa_cpus)) if numa_cpus else max(1, host_threads() // max(1, world)))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
