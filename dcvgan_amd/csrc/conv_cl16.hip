@@ -637,21 +637,24 @@ __global__ __launch_bounds__(256) void cl_col2im_kernel(const ClCol2imArgs a) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // per dim: the taps whose source coordinate exists.  scatter (src = (dst + p - k) / s when divisible): k = k0 + j s with k0 = (dst + p) mod s, src = i0 - j;
+    // direct (src = dst s - p + k): k = j, src = i0 + j.  One division per dim and thread, none in the loops.
     const int o[3] = {(int)od, (int)oh, (int)ow};
-    for (int kd = 0; kd < a.k[0]; ++kd) {
-        int id;
-        if (a.scatter) { const int q = o[0] + a.p[0] - kd; if (q < 0 || q % a.s[0]) continue; id = q / a.s[0]; } else id = o[0] * a.s[0] - a.p[0] + kd;
+    int k0[3], i0[3], kst[3], ist[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (a.scatter) { const int q = o[d] + a.p[d]; k0[d] = q % a.s[d]; i0[d] = q / a.s[d]; kst[d] = a.s[d]; ist[d] = -1; }
+        else { k0[d] = 0; i0[d] = o[d] * a.s[d] - a.p[d]; kst[d] = 1; ist[d] = 1; }
+    }
+    const __bf16* zn = a.z + (int64_t)n * a.s_sp * a.zpitch;
+    for (int kd = k0[0], id = i0[0]; kd < a.k[0]; kd += kst[0], id += ist[0]) {
         if ((unsigned)id >= (unsigned)a.sext[0]) continue;
-        for (int kh = 0; kh < a.k[1]; ++kh) {
-            int ih;
-            if (a.scatter) { const int q = o[1] + a.p[1] - kh; if (q < 0 || q % a.s[1]) continue; ih = q / a.s[1]; } else ih = o[1] * a.s[1] - a.p[1] + kh;
+        for (int kh = k0[1], ih = i0[1]; kh < a.k[1]; kh += kst[1], ih += ist[1]) {
             if ((unsigned)ih >= (unsigned)a.sext[1]) continue;
-            for (int kw = 0; kw < a.k[2]; ++kw) {
-                int iw;
-                if (a.scatter) { const int q = o[2] + a.p[2] - kw; if (q < 0 || q % a.s[2]) continue; iw = q / a.s[2]; } else iw = o[2] * a.s[2] - a.p[2] + kw;
+            const __bf16* zr = zn + ((int64_t)id * a.s_hw + (int64_t)ih * a.s_w) * a.zpitch + ((kd * a.k[1] + kh) * a.k[2]) * a.OC;
+            for (int kw = k0[2], iw = i0[2]; kw < a.k[2]; kw += kst[2], iw += ist[2]) {
                 if ((unsigned)iw >= (unsigned)a.sext[2]) continue;
-                const int t = (kd * a.k[1] + kh) * a.k[2] + kw;
-                const __bf16* zp = a.z + ((int64_t)n * a.s_sp + (int64_t)id * a.s_hw + (int64_t)ih * a.s_w + iw) * a.zpitch + t * a.OC;
+                const __bf16* zp = zr + (int64_t)iw * a.zpitch + kw * a.OC;
                 for (int e = 0; e < a.OC; ++e) acc[e] += (float)zp[e];
             }
         }
