@@ -138,6 +138,13 @@ def lib():
                 if tuple(sizes) != mine:
                     raise NativeError(f"struct sizes differ: library {tuple(sizes)} vs binding {mine} (dcv_dims5, dcv_conv_geom, dcv_wpack)")
                 _lib = l
+                # DCV_PRECISION=fp32|bf16|f32x6: the process default of the MFMA precision (same as set_precision(); lets a whole test run or an unchanged
+                # trainer be put on another precision from outside)
+                env = os.environ.get("DCV_PRECISION")
+                if env:
+                    if env not in ("fp32", "bf16", "f32x6"):
+                        raise NativeError(f"DCV_PRECISION={env!r}: expected fp32, bf16 or f32x6")
+                    l.dcv_set_precision({"fp32": 0, "bf16": 1, "f32x6": 2}[env])
     return _lib
 
 
