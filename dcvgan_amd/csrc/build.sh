@@ -3,19 +3,27 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$HERE/../libdcvgan_hip.so"
+OUT="${DCV_OUT:-$HERE/../libdcvgan_hip.so}"
+OBJ="${DCV_OBJ:-$HERE/obj}"
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs also in the one-wave-per-SIMD kernels (wgrad_dma_kernel): with the
 # default heuristic those get AGPR accumulators, and the compiler moved all 64 of them to VGPRs and back on every tile of the K loop
 # (the conditional fold of the two-level accumulation is VALU code): 128 v_accvgpr moves per 128 MFMAs.
-FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
-mkdir -p "$HERE/obj"
+# -target-feature -packed-fp32-ops: no packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in any kernel.  Measured on MI355X
+# (profiles/r04_packed_fp32/): waves of the small kernels (thin data gradients, BatchNorm, elementwise) that use them gave wrong upper lanes now
+# and then while another stream's bf16-MFMA waves shared their CUs; single-instruction FP32 code of the same kernels did not, in any of the runs.
+# (The host pass prints "not a recognized feature for this target" for it; filtered below.)
+# DCV_PACKED_FP32=1 builds WITH them (into $DCV_OUT), for the A/B of tools/packed_fp32_ab.sh only.
+NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
+[ -n "${DCV_PACKED_FP32:-}" ] && NOPK=""
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$ROOT/include -I$HERE -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form $NOPK"
+mkdir -p "$OBJ"
 pids=()
 for f in conv_mfma elementwise conv_cl16 cl_elementwise; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/dcv_common.h" -nt "$HERE/obj/$f.o" ] || [ "$ROOT/include/dcvgan_hip.h" -nt "$HERE/obj/$f.o" ]; then
-    hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/dcv_common.h" -nt "$OBJ/$f.o" ] || [ "$ROOT/include/dcvgan_hip.h" -nt "$OBJ/$f.o" ]; then
+    hipcc $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$OBJ/$f.o" 2> >(grep -v "not a recognized feature for this target" >&2) &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || exit 1; }; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/obj/conv_mfma.o" "$HERE/obj/elementwise.o" "$HERE/obj/conv_cl16.o" "$HERE/obj/cl_elementwise.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/conv_mfma.o" "$OBJ/elementwise.o" "$OBJ/conv_cl16.o" "$OBJ/cl_elementwise.o"
 echo "built $OUT"

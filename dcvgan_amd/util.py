@@ -32,8 +32,8 @@ def set_precision(module, mode=None):
     configs): "bf16" = bf16 products with fp32 accumulation in this module's convolutions (forward, data and weight gradients), "fp32", or None = follow
     the process default (`dcvgan_amd.native.set_precision`).  Everything else of the module — tensors in HBM, BatchNorm statistics, optimiser — stays fp32."""
     import torch.nn as nn
-    if mode not in (None, "fp32", "bf16"):
-        raise ValueError(f"precision {mode!r}: expected None, 'fp32' or 'bf16'")
+    if mode not in (None, "fp32", "bf16", "f32x6"):
+        raise ValueError(f"precision {mode!r}: expected None, 'fp32', 'bf16' or 'f32x6'")
     for m in module.modules():
         if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)):
             if mode is None:

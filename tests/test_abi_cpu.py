@@ -115,3 +115,27 @@ def test_no_product_import_of_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_library_has_no_packed_fp32_arithmetic(tmp_path):
+    """dcvgan_amd/csrc/build.sh passes -target-feature -packed-fp32-ops (profiles/r04_packed_fp32/SUMMARY.txt: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 code in
+    the small kernels gave wrong upper lanes beside another stream's bf16-MFMA waves).  Checked on the shipped code objects themselves."""
+    import re
+    import shutil
+    import subprocess
+    from dcvgan_amd import native
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(native.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib], capture_output=True, text=True, cwd=str(tmp_path))     # writes lib.so.<n>.hipv4-amdgcn-amd-amdhsa--gfx950 beside it
+    objs = sorted(str(f) for f in tmp_path.iterdir() if "amdgcn" in f.name and "gfx950" in f.name)
+    assert objs, "no gfx950 code object found in the library"
+    mfma = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", o], capture_output=True, text=True).stdout
+        mfma += len(re.findall(r"\bv_mfma_", asm))
+        found = sorted(set(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", asm)))
+        assert not found, f"packed-FP32 arithmetic in a shipped kernel ({os.path.basename(o)}): {found}"
+    assert mfma > 1000, "the disassembly does not look like the library's kernels"
