@@ -559,6 +559,43 @@ int dcv_cl_elementwise(int kind, const void* x, const dcv_dims5* xd, const void*
     return DCV_OK;
 }
 
+// the same from the producing convolution's per-tile fp32 sums stat[part][pitch][2] (dcv_cl_conv_forward_stats): fp64 combine, fixed order
+__global__ __launch_bounds__(256) void cl_bn_finalize_stat_kernel(const float* __restrict__ stat, int nparts, int pitch, int C, double count, float eps, float momentum,
+                                                                  float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                                                  float* __restrict__ mean, float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[2][256];
+    const int c = blockIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const float2 v = *reinterpret_cast<const float2*>(stat + ((int64_t)p * pitch + c) * 2);
+        a1 += (double)v.x; a2 += (double)v.y;
+    }
+    red[0][threadIdx.x] = a1; red[1][threadIdx.x] = a2;
+    __syncthreads();
+#pragma unroll
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double s1 = red[0][0], s2 = red[1][0];
+    if (c == 0 && nbt) *nbt += 1;
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    invstd[c] = is;
+    scale[c] = gamma[c] * is;
+    shift[c] = beta[c] - (float)m * gamma[c] * is;
+    if (rm) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * m);
+        rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * unb);
+    }
+}
+
 // workspace: partials (doubles) + 5 C floats of coefficients
 size_t dcv_cl_bn_workspace_bytes(int channels) { return (size_t)1024 * channels * 2 * sizeof(double) + (size_t)8 * channels * sizeof(float) + 512; }
 
@@ -577,9 +614,32 @@ static int cl_bn_setup(const dcv_dims5* xd, ClBnArgs* a, int* blocks, const char
     return DCV_OK;
 }
 
+static int cl_bn_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                         const float* mask, int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream,
+                         const float* stat, int nparts, int pitch);
+
 int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                           const float* mask, int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+    return cl_bn_forward(x, xd, y, yd, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, mask, training, momentum, eps, act, slope,
+                         ws, ws_bytes, stream, nullptr, 0, 0);
+}
+// training-mode BatchNorm whose statistics come from the producing convolution's epilogue (dcv_cl_conv_forward_stats: `nparts` rows of `pitch` channels x {sum, sum^2}):
+// the pass over x that cl_bn_stats_kernel makes is skipped
+int dcv_cl_bn_act_forward_stats(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                                const float* mask, float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch,
+                                void* ws, size_t ws_bytes, void* stream) {
+    if (!stat || nparts <= 0 || !xd || pitch < xd->c) return fail(DCV_EINVAL, "cl_bn_act_forward_stats: partial sums missing or narrower than the channel count");
+    return cl_bn_forward(x, xd, y, yd, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean, save_invstd, mask, 1, momentum, eps, act, slope,
+                         ws, ws_bytes, stream, stat, nparts, pitch);
+}
+
+static int cl_bn_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                         const float* mask, int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream,
+                         const float* stat, int nparts, int pitch) {
     ClBnArgs a;
     int blocks = 0;
     int rc = cl_bn_setup(xd, &a, &blocks, "cl_bn_act_forward");
@@ -594,7 +654,10 @@ int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv
     a.x = static_cast<const __bf16*>(x); a.y = static_cast<__bf16*>(y); a.partial = partial; a.mask = mask; a.act = act; a.slope = slope;
     a.scale = coef; a.shift = coef + a.C;
     const int cb = (a.C + 63) / 64;
-    if (training) {
+    if (training && stat) {
+        hipLaunchKernelGGL(cl_bn_finalize_stat_kernel, dim3((unsigned)a.C), dim3(256), 0, st, stat, nparts, pitch, a.C, (double)a.P, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, save_mean, save_invstd, gamma, beta, coef, coef + a.C);
+    } else if (training) {
         hipLaunchKernelGGL(cl_bn_stats_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * a.C * 2 * sizeof(double), st, a);
         DCV_LAUNCH_CHECK();
         hipLaunchKernelGGL(cl_bn_finalize_kernel, dim3((unsigned)a.C), dim3(256), 0, st, partial, blocks, a.C, (double)a.P, eps, momentum, running_mean, running_var,

@@ -115,6 +115,9 @@ struct ClGatherArgs {
     uint32_t x_bytes, y_bytes;   // buffer extents (range check = padding and guard)
     int32_t toff[64];            // byte offset of tap t relative to the position's base pixel
     int32_t tsel[64];            // ud | uh << 2 | uw << 4
+    // BatchNorm sums of the stored outputs, left by the epilogue (conv -> BatchNorm pairs, forward, no activation): stat[stat_row0 + position tile][OCp][2] = {sum, sum of squares}
+    float* stat;
+    int32_t stat_row0, pad2;
 };
 struct ClGatherPack {
     ClGatherArgs c[4];
@@ -124,6 +127,18 @@ struct ClGatherPack {
 __device__ __forceinline__ float cl_act(float v, int act, float slope) {
     if (act == DCV_ACT_LEAKY) return v > 0.f ? v : v * slope;
     if (act == DCV_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// sum over each 32-lane half of the wave, valid in lanes 16-31 / 48-63 (five DPP adds; the fp32 path's half_wave_sum)
+__device__ __forceinline__ float cl_half_wave_sum(float v) {
+#define CL_DPP(X, CTRL, ROWS) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, X), CTRL, ROWS, 0xf, false))
+    v += CL_DPP(v, 0xB1, 0xf);     // quad_perm [1,0,3,2]
+    v += CL_DPP(v, 0x4E, 0xf);     // quad_perm [2,3,0,1]
+    v += CL_DPP(v, 0x141, 0xf);    // row_half_mirror
+    v += CL_DPP(v, 0x140, 0xf);    // row_mirror
+    v += CL_DPP(v, 0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+#undef CL_DPP
     return v;
 }
 
@@ -335,6 +350,36 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
                 o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
                 __builtin_amdgcn_raw_buffer_store_b64(o, yrs, v2, 0, 0);
             }
+    }
+    if (a.stat) {
+        // conv -> BatchNorm pairs: {sum, sum of squares} of this tile's STORED values (the bf16 roundings, as the BatchNorm op's own pass would read them), per channel.
+        // Rows of padding positions and of channels past OC hold exact zeros (zero operands).  Half-wave sums by DPP, the WM waves of a channel row meet in LDS and are
+        // added in a fixed order: stat[(stat_row0 + m tile)][OCp][2], every row written by exactly one workgroup.
+        __syncthreads();                                     // every wave has left the K loop: the stage buffers are free
+        float* sred = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TOC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < TM; ++j) { const float v = (float)(__bf16)acc[i][j][r]; s1 += v; s2 += v * v; }
+                s1 = cl_half_wave_sum(s1);
+                s2 = cl_half_wave_sum(s2);
+                if (l31 == 31) {
+                    const int ocl = (woc * TOC + i) * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+                    sred[(wm * BN + ocl) * 2] = s1;
+                    sred[(wm * BN + ocl) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        float* __restrict__ dst = a.stat + ((int64_t)(a.stat_row0 + m_t) * a.OCp + oc0) * 2;
+        for (int e = threadIdx.x; e < 2 * BN; e += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += sred[w * BN * 2 + e];
+            dst[e] = t;
+        }
     }
 }
 #undef CL_ISSUE
@@ -929,8 +974,13 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     return DCV_OK;
 }
 
+// `stat` (forward, no activation, no accumulation, a full-channel destination): per-tile BatchNorm sums from the epilogue, *nparts rows of *pitch channels x {sum, sum^2};
+// *nparts stays 0 where the form does not produce them (thin destinations) and the caller's BatchNorm op takes its own statistics.
 static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, const dcv_dims5* xd, const void* packed, void* dst_p, const dcv_dims5* yd,
-                       int act, float slope, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                       int act, float slope, int accumulate, void* ws, size_t ws_bytes, void* stream,
+                       float* stat = nullptr, size_t stat_bytes = 0, int* nparts = nullptr, int* pitch = nullptr) {
+    if (nparts) *nparts = 0;
+    if (pitch) *pitch = 0;
     if (!g || !xd || !yd || !src_p || !packed || !dst_p) return fail(DCV_EINVAL, "cl conv: null pointer");
     ClPlan pl;
     int rc = cl_make_plan(which, g, xd, yd, &pl);
@@ -996,10 +1046,20 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
         if (++n > 4) return fail(DCV_EUNSUPPORTED, "cl conv: more than 4 position classes");
     }
     if (n == 0) return DCV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stat && which == 0 && act == DCV_ACT_NONE && !accumulate) {
+        const size_t need = (size_t)n * maxtm * OCp * 2 * sizeof(float);
+        if (need <= stat_bytes) {
+            // rows of position tiles a class does not have (classes of different sizes) must read as zero
+            DCV_HIP_CHECK(hipMemsetAsync(stat, 0, need, st));
+            for (int i = 0; i < n; ++i) { pk.c[i].stat = stat; pk.c[i].stat_row0 = (int32_t)(i * maxtm); }
+            if (nparts) *nparts = (int)(n * maxtm);
+            if (pitch) *pitch = OCp;
+        }
+    }
     for (int i = n; i < 4; ++i) pk.c[i] = pk.c[0];
     pk.ncls = n; pk.tiles_oc = OCp / tc.bn; pk.tiles_m = (int)maxtm;
     const dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (tc.bn == 128) cl_launch_gather<2, 2, 2, 2>(pk, thin, grid, st);
     else if (tc.bn == 64) cl_launch_gather<2, 2, 1, 4>(pk, thin, grid, st);
     else cl_launch_gather<1, 2, 1, 4>(pk, thin, grid, st);
@@ -1011,6 +1071,28 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
 int dcv_cl_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
                         int act, float slope, void* ws, size_t ws_bytes, void* stream) {
     return cl_conv_run(0, g, x, xd, packed, y, yd, act, slope, 0, ws, ws_bytes, stream);
+}
+// bytes of the per-tile BatchNorm sums dcv_cl_conv_forward_stats leaves (0: this geometry's form does not produce them)
+size_t dcv_cl_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* xd, const dcv_dims5* yd) {
+    if (!g || !xd || !yd) return 0;
+    ClPlan pl;
+    if (cl_make_plan(0, g, xd, yd, &pl) != DCV_OK || cl_thin_out(pl, g)) return 0;
+    const ClTile tc = cl_pick_tile(pl.OC);
+    const int OCp = (pl.OC + tc.bn - 1) / tc.bn * tc.bn;
+    int n = 0;
+    int64_t maxtm = 0;
+    for (const ClClass& c : pl.cls) {
+        if (c.t[0].n * c.t[1].n * c.t[2].n == 0 || c.o_ext[0] <= 0 || c.o_ext[1] <= 0 || c.o_ext[2] <= 0) continue;
+        const int64_t M64 = (int64_t)yd->n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
+        maxtm = std::max<int64_t>(maxtm, (M64 + tc.bm - 1) / tc.bm);
+        ++n;
+    }
+    return (size_t)n * maxtm * OCp * 2 * sizeof(float);
+}
+int dcv_cl_conv_forward_stats(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
+                              float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream) {
+    if (!stat || !nparts || !pitch) return fail(DCV_EINVAL, "cl_conv_forward_stats: null pointer");
+    return cl_conv_run(0, g, x, xd, packed, y, yd, DCV_ACT_NONE, 0.f, 0, ws, ws_bytes, stream, stat, stat_bytes, nparts, pitch);
 }
 int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
                               int accumulate, void* ws, size_t ws_bytes, void* stream) {

@@ -62,7 +62,8 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, part
         mask = rng.dropout2d_mask(x.shape[0], x.shape[1], dropout.p, x.device)
     if ops_cl.is_cl(x):     # bf16 channels-last data path (ops_cl): statistics from its own pass over the bf16 tensor
         return ops_cl.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
-                             bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, num_batches_tracked=bn.num_batches_tracked if training else None)
+                             bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, num_batches_tracked=bn.num_batches_tracked if training else None,
+                             partials=partials if training else None)
     # num_batches_tracked is bumped by the statistics kernel itself (one launch less per BatchNorm layer)
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
                       bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, partials=partials if training else None,
@@ -84,7 +85,9 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             # bf16 channels-last data path: the same grouping (conv [+ activation] in one launch), ops_cl's kernels
             fused = _act_of(nxt) if nxt is not None else None
             last = i + (2 if fused is not None else 1) >= n
-            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None, grad_slot=grad_slot if i == 0 else None)
+            box = [] if (fused is None and isinstance(nxt, _BNS) and nxt.training and _FUSE_BN_STATS) else None
+            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None, grad_slot=grad_slot if i == 0 else None, bn_stats=box)
+            pending = box[0] if box else None
             i += 2 if fused is not None else 1
         elif isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None

@@ -16,7 +16,11 @@ from torch.autograd import Function
 
 from . import native as N
 from .native import ACT_LEAKY, ACT_NONE, ConvGeom, check, dims5, lib, ptr, stream_ptr
-from .ops import _Out, _out_shape, _ws
+import os
+
+from .ops import _Opaque, _Out, _out_shape, _ws
+
+_FUSE_BN_STATS = os.environ.get("DCV_NO_BN_FUSION") is None
 
 BF16 = torch.bfloat16
 _ENABLED = [False]
@@ -201,7 +205,7 @@ def _packed(w: torch.Tensor, which: int, g: ConvGeom, xd, yd, key_dims):
 
 class _ConvCl(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, grad_slot=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, grad_slot=None, bn_stats=None):
         _req(x, "conv input"); N._require(w, "conv weight")
         ctx.grad_slot = grad_slot
         if x.shape[1] != g.cin:
@@ -213,7 +217,17 @@ class _ConvCl(Function):
         xd, yd = dims5(x), dims5(y)
         pk = _packed(w, 0, g, xd, yd, tuple(x.shape))
         wsp, wsn = _ws("clconv", lib().dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0), x.device)
-        check(lib().dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_cl_conv_forward")
+        sbytes = lib().dcv_cl_conv_stats_bytes(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE and _FUSE_BN_STATS) else 0
+        if sbytes:
+            # conv -> BatchNorm pair: the epilogue leaves per-tile {sum, sum^2} of the stored bf16 values, the BatchNorm op skips its statistics pass over y
+            stat = torch.empty(sbytes // 4, dtype=torch.float32, device=x.device)
+            nparts, pitch = C.c_int(0), C.c_int(0)
+            check(lib().dcv_cl_conv_forward_stats(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), ptr(stat), sbytes, C.byref(nparts), C.byref(pitch),
+                                                  wsp, wsn, stream_ptr()), "dcv_cl_conv_forward_stats")
+            if nparts.value > 0:
+                bn_stats.append((stat, nparts.value, pitch.value))
+        else:
+            check(lib().dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_cl_conv_forward")
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -250,13 +264,14 @@ class _ConvCl(Function):
                 raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + L.dcv_last_error().decode())
             wsp, wsn = _ws("clconv", need, x.device)
             check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, grad_slot=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, grad_slot=None, bn_stats=None):
     """y = act(conv(x, w)) on CL16 tensors; fp32 weights in torch layout; `out`: destination view (a channel slice of a concat buffer);
-    `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection)."""
-    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out), grad_slot)
+    `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection); `bn_stats`: a list that receives (buffer, nparts, pitch) when the
+    epilogue produced the following BatchNorm's sums (conv -> BatchNorm pairs in training mode, no activation in between)."""
+    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out), grad_slot, bn_stats)
 
 
 # --------------------------------------------------------------------------- #
@@ -264,7 +279,7 @@ def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, g
 # --------------------------------------------------------------------------- #
 class _BnActCl(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training, momentum, eps, act, slope, out=None, nbt=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training, momentum, eps, act, slope, out=None, nbt=None, partials=None):
         _req(x, "bn input")
         L = lib()
         Cn = x.shape[1]
@@ -272,9 +287,15 @@ class _BnActCl(Function):
         stats = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         xd, yd = dims5(x), dims5(y)
         wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
-        check(L.dcv_cl_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                      ptr(nbt) if training else None, ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope,
-                                      wsp, wsn, stream_ptr()), "dcv_cl_bn_act_forward")
+        if partials is not None and training:
+            stat, nparts, pitch = partials.v
+            check(L.dcv_cl_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                ptr(nbt), ptr(stats[0]), ptr(stats[1]), ptr(mask), momentum, eps, act, slope, ptr(stat), nparts, pitch,
+                                                wsp, wsn, stream_ptr()), "dcv_cl_bn_act_forward_stats")
+        else:
+            check(L.dcv_cl_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                          ptr(nbt) if training else None, ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope,
+                                          wsp, wsn, stream_ptr()), "dcv_cl_bn_act_forward")
         ctx.cfg = (bool(training), act, slope)
         ctx.save_for_backward(x, gamma, beta, stats, mask)
         return y
@@ -292,13 +313,14 @@ class _BnActCl(Function):
         wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
         check(L.dcv_cl_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]),
                                        ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()), "dcv_cl_bn_act_backward")
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0, mask=None, momentum: float = 0.1,
-           eps: float = 1e-5, out=None, num_batches_tracked=None):
+           eps: float = 1e-5, out=None, num_batches_tracked=None, partials=None):
+    """`partials`: (buffer, nparts, pitch) left by the producing convolution's epilogue (conv(..., bn_stats=[]))."""
     return _BnActCl.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope),
-                          None if out is None else _Out(out), num_batches_tracked)
+                          None if out is None else _Out(out), num_batches_tracked, None if partials is None else _Opaque(partials))
 
 
 # --------------------------------------------------------------------------- #

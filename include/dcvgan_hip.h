@@ -271,6 +271,12 @@ int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
 size_t dcv_cl_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which);
 int dcv_cl_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
                         int act, float slope, void* ws, size_t ws_bytes, void* stream);
+/* conv -> BatchNorm pairs in training mode (as dcv_conv_forward_stats on the fp32 path): the epilogue also leaves {sum, sum of squares} of the STORED bf16 values per position tile
+ * and output channel: *nparts rows of *pitch channels x 2 floats in `stat` (dcv_cl_conv_stats_bytes; 0 = this geometry's form produces none, and *nparts stays 0: the BatchNorm op
+ * then makes its own pass).  dcv_cl_bn_act_forward_stats consumes them. */
+size_t dcv_cl_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
+int dcv_cl_conv_forward_stats(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd,
+                              float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream);
 int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
                               int accumulate, void* ws, size_t ws_bytes, void* stream);
 size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
@@ -290,6 +296,10 @@ size_t dcv_cl_bn_workspace_bytes(int channels);
 int dcv_cl_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
                           const float* mask, int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int dcv_cl_bn_act_forward_stats(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                                const float* mask, float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch,
+                                void* ws, size_t ws_bytes, void* stream);
 int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, const dcv_dims5* xd, void* dx, const dcv_dims5* dxd,
                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const float* mask,
                            int training, int act, float slope, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);

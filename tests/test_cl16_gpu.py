@@ -357,3 +357,37 @@ def test_iteration_cl16_is_bitwise_reproducible():
         ops_cl.enable(False)
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("case", [("conv2d_64_128", False, 2, 64, 128, 4, 2, 1, (16, 16), 5), ("convT2d_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3),
+                                  ("conv3d_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2), ("conv2d_thin3_32", False, 2, 3, 32, 4, 2, 1, (64, 64), 2),
+                                  ("convT2d_latent_50_128", True, 2, 50, 128, 4, 1, 0, (1, 1), 9)], ids=lambda c: c[0])
+def test_bn_sums_from_the_conv_epilogue_cl16(case):
+    """conv -> BatchNorm pairs: the convolution's epilogue leaves per-tile {sum, sum^2} of the STORED bf16 values and the BatchNorm op skips its own pass over them.
+    Same statistics as that pass (fp64 combine of fp32 partial sums against fp64 combine of bounded fp32 runs): running statistics to 1e-6, and the normalised
+    output differs in at most a few last-bit roundings."""
+    from dcvgan_amd import native as N, ops, ops_cl
+    name, tr, dims, cin, cout, k, s, p, sp, n = case
+    g0 = torch.Generator().manual_seed(7)
+    kk = (k,) * dims if isinstance(k, int) else k
+    ss = (s,) * dims if isinstance(s, int) else s
+    pp = (p,) * dims if isinstance(p, int) else p
+    x = ops_cl.from_f32(torch.randn((n, cin) + sp, generator=g0).to(DEV))
+    w = (torch.randn(((cin, cout) if tr else (cout, cin)) + kk, generator=g0) * 0.05).to(DEV)
+    gamma = (torch.rand(cout, generator=g0) + 0.5).to(DEV); beta = (torch.randn(cout, generator=g0) * 0.1).to(DEV)
+    geom = ops.conv_geom(w, ss, pp, tr)
+    res = []
+    for fused in (True, False):
+        box = [] if fused else None
+        y = ops_cl.conv(x, w, geom, bn_stats=box)
+        if fused:
+            assert len(box) == 1 and box[0][1] > 0, "the epilogue produced no sums for this geometry"
+        rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        z = ops_cl.bn_act(y, gamma, beta, rm, rv, True, ops.ACT_LEAKY, 0.2, partials=box[0] if fused else None, num_batches_tracked=nbt)
+        res.append((y.float().clone(), z.float().clone(), rm.clone(), rv.clone(), int(nbt)))
+    (y1, z1, rm1, rv1, n1), (y0, z0, rm0, rv0, n0) = res
+    assert torch.equal(y1, y0)                       # the convolution's own output is untouched by the extra epilogue
+    assert n1 == n0 == 1
+    assert rel(rm1, rm0) < 1e-6 and rel(rv1, rv0) < 1e-6, (rel(rm1, rm0), rel(rv1, rv0))
+    assert rel(z1, z0) < 1e-4 and float((z1 != z0).float().mean()) < 2e-2, (rel(z1, z0), float((z1 != z0).float().mean()))

@@ -16,7 +16,11 @@ LANES = (sys.argv[5] != "0") if len(sys.argv) > 5 else True
 ITERS = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 ONLY = [a.split("=")[1].split(",") for a in sys.argv if a.startswith("only=")]      # only=idis,vdis: `precision` on those modules, fp32 elsewhere
 native.lib()
-native.set_precision("fp32" if ONLY else mode)
+if mode == "bf16cl":          # the bf16 channels-last data path (ops_cl) instead of an MFMA precision of the fp32 tensors
+    from dcvgan_amd import ops_cl
+    ops_cl.enable(True)
+else:
+    native.set_precision("fp32" if ONLY else mode)
 if "record=1" in sys.argv:       # experiment: every gradient entering a custom backward is recorded on the stream that will read it
     import inspect
     from dcvgan_amd import ops as _ops
