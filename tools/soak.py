@@ -35,7 +35,9 @@ for i in range(N):
                       {k: round(float(v), 4) for k, v in out.items()}))
 for m in marks:
     print("iter %4d  allocated %.1f MB  reserved %.1f MB  host maxrss %.1f MB  %s" % m)
-assert abs(marks[-1][1] - marks[1][1]) < 4.0 * max(1, B // 16), "device memory grows"   # (tensors that crossed streams are released an event later: +-1 MB at the sample point)
+# (tensors that crossed streams are released an event later: +-1 MB at the sample point; iterations whose D update is gated off hold ~4 MB less at B = 16 than the others,
+#  and the marks fall on both kinds)
+assert abs(marks[-1][1] - marks[1][1]) < 8.0 * max(1, B // 16), "device memory grows"
 assert marks[-1][3] - marks[1][3] < 64, "host memory grows"
 assert all(v == v and abs(v) < 1e3 for v in marks[-1][4].values())
 print(f"soak ok ({CFG}, {MODE}, B = {B}, {N} iterations)")
