@@ -8,6 +8,8 @@ in-range offset inside a raw-buffer descriptor would read a neighbour silently.
   * a batch-split identity over ALL FIVE models of surreal-depth1 and isogd-flow: in eval mode rows 0..15 of a B = 100 pass — ggen and
     cgen outputs, the three discriminators' logits, every parameter gradient for a cotangent that is zero outside those rows — equal the
     B = 16 pass (the size tests/test_fullwidth_gpu.py verifies against the oracle)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -118,7 +120,7 @@ def test_batch_split_identity_b100(dev, name):
     from tests import fullwidth as FW
     cfg = CONFIGS[name]
     assert cfg.batchsize == B
-    torch.manual_seed(78)
+    torch.manual_seed(int(os.environ.get("DCV_TEST_SEED", "78")))      # (the environment override is for seed sweeps with DCV_REPORT_DIR)
     models = trainer.build_models(cfg, dev)
     g = torch.Generator(device=dev).manual_seed(4)
     for m in models.values():      # non-trivial running statistics, then eval mode: every sample is processed on its own
@@ -129,6 +131,9 @@ def test_batch_split_identity_b100(dev, name):
         m.eval()
     ggen, cgen, idis, vdis, gdis = (models[k] for k in ("ggen", "cgen", "idis", "vdis", "gdis"))
     t, Cg = 9, cfg.channel
+    for k in filter(None, os.environ.get("DCV_FP32_MODULES", "").split(",")):      # diagnosis: these modules at native fp32 whatever the process default
+        from dcvgan_amd import util
+        util.set_precision(models[k], "fp32")
 
     def draws(n):
         """The same random numbers for sample i whatever the batch, in the models' draw order: ggen z_content, h0, e_1..e_16
@@ -180,6 +185,7 @@ def test_batch_split_identity_b100(dev, name):
         sum((y * c.double()).sum() for y, c in zip(ys, cots(ys))).backward()
         grads = {(mn, k): p.grad.detach() for mn in st for k, p in st[mn].items() if p.requires_grad}
         flips = sum(m[0] for m in tape.mismatch); total = sum(m[1] for m in tape.mismatch); far = max(m[2] for m in tape.mismatch)
+        oracle64.per_activation = [tuple(m[:3]) for m in tape.mismatch]
         return xg.detach(), xc.detach(), [y.detach() for y in ys], grads, (flips, total, far)
 
     xg16, xc16, ys16, gr16, k16 = run(16)
@@ -197,6 +203,15 @@ def test_batch_split_identity_b100(dev, name):
         assert flips <= max(8, KINK_FRAC * total) and far <= KINK_EPS, (tag, flips, total, far)
         assert rel(xgB if tag == "B=100" else xg16, oxg) < 1e-5 and rel(xcB if tag == "B=100" else xc16, oxc) < 1e-5
         worst = max((rel(grads[key], gref), key) for key, gref in ogr.items())
+        if os.environ.get("DCV_REPORT_DIR"):     # every parameter's gradient against the fp64 replay, for comparing precision modes
+            os.makedirs(os.environ["DCV_REPORT_DIR"], exist_ok=True)
+            with open(os.path.join(os.environ["DCV_REPORT_DIR"], f"b100_split_{name}_{os.environ.get('DCV_PRECISION', 'fp32')}_seed{os.environ.get('DCV_TEST_SEED', '78')}_{tag.replace('=', '')}.txt"), "w") as f:
+                f.write("# per recorded activation pattern, in forward order: (elements where the fp64 replay's own sign differs, elements, their largest normalised distance from zero)\n")
+                f.write("# " + " ".join("%d/%d/%.1e" % m for m in oracle64.per_activation) + "\n")
+                for key, gref in sorted(ogr.items(), key=lambda kv: -rel(grads[kv[0]], kv[1])):
+                    f.write("%-8s %-40s %.3e  |g| %.3e\n" % (key[0], key[1], rel(grads[key], gref), float(gref.norm())))
+            if os.environ.get("DCV_REPORT_ONLY"):
+                continue
         assert worst[0] < 1e-4, (tag, worst, differing)
         assert len(ogr) == 83          # every parameter tensor of the five models
     assert differing <= 64, differing

@@ -1,5 +1,6 @@
-"""One layer (default vdis.5: conv3d 128 -> 256, 4x4x4, stride (1,2,2)), forward and data gradient: native fp32 kernels and the f32x6 mode against torch's fp64 on the host.
-Usage: python tools/x6_truth_probe.py [B]"""
+"""Three layers, forward / data gradient / weight gradient: native fp32 kernels, f32x6 and bf16 products against torch's fp64 — relative L2 error AND its bias
+(mean signed error in units of std / sqrt(N): ~0 for a rounding that is unbiased) and the error of per-channel SUMS of the output, which a bias hits coherently
+(BatchNorm statistics and BatchNorm-parameter gradients are such sums).  Usage: python tools/x6_truth_probe.py [B] [gpu64]"""
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -35,8 +36,16 @@ for name, xs, ws, s, p in cases:
         xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
         y = ops.conv(xd, wd, ops.conv_geom(wd, s, p, False))
         dx, dw = torch.autograd.grad(y, [xd, wd], dy.to(dev))
-        row.append((m, rel(y.detach(), y64), rel(dx, dx64), rel(dw, dw64)))
+        def bias(a, b):
+            e = a.double().cpu() - b
+            return float(e.mean() / e.std() * e.numel() ** 0.5)
+
+        def chsum(a, b):
+            dims = tuple(i for i in range(b.dim()) if i != 1)
+            return float((a.double().cpu().sum(dims) - b.sum(dims)).norm() / b.sum(dims).norm())
+        row.append((m, rel(y.detach(), y64), rel(dx, dx64), rel(dw, dw64), bias(y.detach(), y64), bias(dx, dx64), chsum(y.detach(), y64), chsum(dx, dx64)))
     print(name, " K =", ws[1] * ws[2] * ws[3] * (ws[4] if len(ws) == 5 else 1))
-    for m, a, b_, c in row:
-        print("    %-6s forward %.3e   data gradient %.3e   weight gradient %.3e   (relative L2 against fp64)" % (m, a, b_, c))
+    for m, a, b_, c, ba, bb, ca, cb in row:
+        print("    %-6s forward %.3e   data gradient %.3e   weight gradient %.3e   (relative L2 against fp64);  bias of the error, forward %+7.1f  data gradient %+7.1f (x std / sqrt N);"
+              "  per-channel sums, forward %.3e  data gradient %.3e" % (m, a, b_, c, ba, bb, ca, cb))
 N.set_precision("fp32")
