@@ -92,6 +92,15 @@ __device__ __forceinline__ void split3_bf16x8(const float (&t)[8], bf16x8 (&o)[3
     }
     o[0] = __builtin_bit_cast(bf16x8, h); o[1] = __builtin_bit_cast(bf16x8, m); o[2] = __builtin_bit_cast(bf16x8, l);
 }
+// The bf16 MFMA's accumulate is not round-to-nearest: what it drops of a sum is dropped toward minus infinity (measured: the mean error of an f32x6 output sits ~1.4 ulp below
+// zero at K = 8192 where the fp32 MFMA's is zero; profiles/r04_f32x6_bias.txt), and sums over outputs — BatchNorm statistics, BatchNorm-parameter gradients — collect that.
+// Cancelled by alternating the SIGN of what is being accumulated: K steps come in phases of 8; in the odd phases the packed weights are negated (pack_weights_kernel) and the
+// accumulators hold MINUS the running sum (negated at each phase change: 16 TOC TM sign flips per 8 steps of 6 TOC TM MFMAs), so the truncation pulls the sum up as often as down.
+#ifdef DCV_X6_NO_PHASES      // A/B builds only (tools/ab_lib.sh): the emulation as first built, with its one-sided error
+#define X6_PHASE(IT) false
+#else
+#define X6_PHASE(IT) ((((IT) >> 3) & 1) != 0)
+#endif
 // the six products, smallest terms first (a = the A operand's pieces, b = the B operand's)
 #define DCV_MFMA_X6(ACC, A3, B3)                                                              \
     {                                                                                         \
@@ -809,7 +818,9 @@ __global__ __launch_bounds__(256, (BF == 2 ? 3 : 4)) void gather_gemm_dma_kernel
 #ifdef DCV_STAMP
     const unsigned long long q_pro = clock64();
 #endif
+    [[maybe_unused]] bool x6_neg = false;   // BF == 2: the accumulators currently hold minus the running sum
     for (int j = j0; j < nst; buf ^= 1) {
+        [[maybe_unused]] const int it_cur = DCV_IT(j);
         int nx = j + 1;
         if constexpr (DSTEP)
             while (nx < nst && !DCV_STEP_LIVE(DCV_IT(nx))) ++nx;
@@ -847,6 +858,15 @@ __global__ __launch_bounds__(256, (BF == 2 ? 3 : 4)) void gather_gemm_dma_kernel
             // position column jj + 1 is split (44 VALU operations) in the shadow of column jj's 6 TOC MFMAs: an MFMA holds the matrix pipe for 32
             // cycles and the vector issue for 8 of them, so ~4 operations behind each one issue for free; only column 0's split is exposed
             split3_bf16x8(tb[0], b8[0]);
+            if (X6_PHASE(it_cur) != x6_neg) {   // phase change (wave-uniform): flip the accumulators' sign
+                x6_neg = !x6_neg;
+#pragma unroll
+                for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TM; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][jj][r] = -acc[i][jj][r];
+            }
 #pragma unroll
             for (int jj = 0; jj < TM; ++jj) {
                 if (jj + 1 < TM) split3_bf16x8(tb[jj + 1 < TM ? jj + 1 : 0], b8[jj + 1 < TM ? jj + 1 : 0]);
@@ -938,6 +958,16 @@ __global__ __launch_bounds__(256, (BF == 2 ? 3 : 4)) void gather_gemm_dma_kernel
     const unsigned long long q_fw = clock64();
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    if constexpr (BF == 2) {
+        if (x6_neg) {
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int jj = 0; jj < TM; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jj][r] = -acc[i][jj][r];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the repeated last-step DMAs must land before LDS is released
 #ifdef DCV_STAMP
     const unsigned long long q_epi = clock64();
@@ -1577,6 +1607,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, const PackArgs 
     float v = 0.f;
     if (oc < OC && !(e.tapsel >> 31)) v = w[(int64_t)oc * ws_o + e.w_off];
     if (pa.fmt[c] == 2) {   // the same RNE split as split3_bf16x8
+        // K steps whose X6_PHASE bit is set carry NEGATED weights: the kernel keeps its accumulators negated while it runs them (see X6_PHASE)
+        if (X6_PHASE(k >> 4)) v = -v;
         __bf16* o = reinterpret_cast<__bf16*>(pa.wp[c]);
         const __bf16 hi = (__bf16)v;
         const float r = v - (float)hi;

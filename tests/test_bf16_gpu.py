@@ -216,3 +216,29 @@ def test_pack_precision_stamp():
     n0 = native.launch_count()
     rc = L.dcv_conv_forward(C.byref(g_x6), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), 0, 0.0, C.byref(pk), ptr(ws), ws.numel(), stream_ptr())
     assert rc == -1 and b"dcv_wpack.precision" in L.dcv_last_error() and native.launch_count() == n0
+
+
+def test_f32x6_error_is_not_one_sided(f32x6):
+    """The bf16 MFMA's accumulate drops what it drops toward minus infinity; the emulation's six small-addend MFMAs per 16 k made that a visible bias of the OUTPUT
+    (mean error ~400 standard errors below zero at K = 8192; per-channel sums of an output 20x further from fp64 than the native kernels': profiles/r04_f32x6_bias.txt).
+    The kernels now alternate the sign of what they accumulate in phases of 8 K steps (X6_PHASE, csrc/conv_mfma.hip).  Forward and data gradient of the video
+    discriminator's conv3d 128 -> 256 (K = 8192) against torch's fp64: the mean signed error within 40 standard errors of zero, channel sums to 2e-6."""
+    from dcvgan_amd import ops
+    dev = f32x6
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 128, 10, 16, 16, generator=g); w = torch.randn(256, 128, 4, 4, 4, generator=g) * 0.05
+    with torch.backends.cudnn.flags(enabled=False):        # torch's own fp64 convolution on the device
+        xr = x.double().to(dev).requires_grad_(True)
+        y64 = F.conv3d(xr, w.double().to(dev), None, (1, 2, 2), (0, 1, 1))
+        dy = torch.randn(y64.shape, generator=g)
+        (dx64,) = torch.autograd.grad(y64, [xr], dy.double().to(dev))
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.conv(xd, w.to(dev), ops.conv_geom(w.to(dev), (1, 2, 2), (0, 1, 1), False))
+    (dx,) = torch.autograd.grad(y, [xd], dy.to(dev))
+    for name, a, b in (("forward", y.detach(), y64.detach()), ("data gradient", dx, dx64)):
+        e = a.double() - b
+        bias = float(e.mean() / e.std() * e.numel() ** 0.5)
+        dims = (0, 2, 3, 4)
+        sums = float((a.double().sum(dims) - b.sum(dims)).norm() / b.sum(dims).norm())
+        assert float(e.norm() / b.norm()) < 2e-6, name
+        assert abs(bias) < 40 and sums < 2e-6, (name, bias, sums)
