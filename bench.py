@@ -478,7 +478,7 @@ def main():
                 native.set_precision("fp32")
             torch.cuda.empty_cache()
         secondary["note"] = ("NOT the headline: bf16cl = bf16 channels-last data path (activations / gradients bf16 in HBM, fp32 masters, statistics, accumulation, optimiser; "
-                             "tolerance tests tests/test_cl16_gpu.py); f32x6 = fp32 emulated on the bf16 matrix pipe in the forward / data-gradient GEMMs (experimental); DESIGN §8")
+                             "tolerance tests tests/test_cl16_gpu.py); f32x6 = fp32 emulated on the bf16 matrix pipe in the forward / data-gradient GEMMs (3-way bf16 split, six products, sign-alternating accumulation; the fp32 parity suites pass with it as the process default; experimental, not the default); DESIGN §8")
 
     if rank == 0:
         per_step = dt / a.steps
