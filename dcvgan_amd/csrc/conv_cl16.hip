@@ -639,6 +639,41 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduc
     a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
 }
 
+// The same reduction walked in SLAB order: a workgroup owns EL consecutive slab elements and GR groups of slabs (EL x GR = 256 threads); a thread sums slabs g, g + GR, ... of its
+// element (consecutive lanes read consecutive floats: whole 64- or 256-byte runs instead of one dword per lane 64 KB apart), the groups meet in LDS and are added in a fixed
+// order, and the element is written once to its place in the torch-layout gradient.  Fixed order throughout: bitwise reproducible.
+template <int EL, int GR>
+__global__ __launch_bounds__(256) void cl_wgrad_reduce_slab_kernel(const ClWgradReduceArgs a) {
+    static_assert(EL * GR == 256, "256 threads");
+    __shared__ float part[GR][EL];
+    const int el = threadIdx.x % EL, g = threadIdx.x / EL;
+    const int64_t nel = (int64_t)a.tiles * (128 * 128);
+    const int64_t e = (int64_t)blockIdx.x * EL + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < nel) {
+        const float* p = a.slab + e;
+        int k = g;
+        for (; k + 3 * GR < a.S; k += 4 * GR) {      // four loads in flight, each into its own fixed partial sum
+            s0 += p[(int64_t)k * nel]; s1 += p[(int64_t)(k + GR) * nel]; s2 += p[(int64_t)(k + 2 * GR) * nel]; s3 += p[(int64_t)(k + 3 * GR) * nel];
+        }
+        for (; k < a.S; k += GR) s0 += p[(int64_t)k * nel];
+    }
+    part[g][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g != 0 || e >= nel) return;
+    float s = part[0][el];
+#pragma unroll
+    for (int q = 1; q < GR; ++q) s += part[q][el];
+    // slab element -> (dense channel, gathered channel, tap): the inverse of cl_wgrad_reduce_kernel's addressing
+    const int tile = (int)(e >> 14), r = (int)((e >> 7) & 127), vc = (int)(e & 127);
+    const int j_t = tile / a.tiles_d, d_t = tile - j_t * a.tiles_d;
+    const int tg = j_t / a.gblocks, gbk = j_t - tg * a.gblocks;
+    const int tl = vc / a.gcb, gcl = vc - tl * a.gcb;
+    const int dc = d_t * 128 + r, gc = gbk * 128 + gcl, t = tg * a.ntpt + tl;
+    if (dc >= a.DC || gc >= a.GC || tl >= a.ntpt || t >= a.T) return;
+    a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
+}
+
 struct ClPackThinArgs {
     __bf16* wp;
     int32_t nsteps, OCg, OCgp, C, OC, T;   // K steps (C / 32 blocks), T * OC GEMM columns, padded, source channels, real output channels, taps
@@ -825,9 +860,10 @@ static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_d
     p->tiles_d = (pad8(D.c) + 127) / 128;
     p->tiles_j = (p->T + p->ntpt - 1) / p->ntpt * p->gblocks;
     p->tiles = p->tiles_d * p->tiles_j;
-    // position splits: ~1024 workgroups (one round of 4 per CU) however few tiles the op has, at least 16 K steps (512 positions) each; measured over the
-    // surreal-depth1 layer table: 13.8 ms of weight gradients per iteration at 1024, 15.9 at 2048, 20.1 at 4096 (slab traffic)
-    static const int64_t target = getenv("DCV_CL_WGRAD_WGS") ? atoll(getenv("DCV_CL_WGRAD_WGS")) : 1024;
+    // position splits: ~768 workgroups (three per CU) however few tiles the op has, at least 16 K steps (512 positions) each; measured over the
+    // surreal-depth1 layer table with the first reduce kernel: 13.8 ms of weight gradients per iteration at 1024, 15.9 at 2048, 20.1 at 4096 (slab traffic); with the
+    // slab-order reduce, whole iterations on one box: 48.6 / 48.2 / 48.9 / 48.6 ms at 640 / 768 / 896 / 1024 (surreal-depth1), 41.8 / 41.6 / 42.1 / 42.1 (isogd-depth)
+    static const int64_t target = getenv("DCV_CL_WGRAD_WGS") ? atoll(getenv("DCV_CL_WGRAD_WGS")) : 768;
     int64_t S = (target + p->tiles - 1) / p->tiles;
     const int64_t maxS = std::max<int64_t>(1, p->M / 512);
     S = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S, maxS), 2048));
@@ -1181,8 +1217,16 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
         a.slab = slab; a.dw = dw; a.S = p.S; a.tiles = p.tiles; a.tiles_d = p.tiles_d; a.gblocks = p.gblocks; a.gcb = p.gcb; a.ntpt = p.ntpt; a.T = p.T;
         a.DC = D.c; a.GC = G.c; a.ws_d = (int64_t)G.c * p.T;
         const int64_t tot = (int64_t)D.c * G.c * p.T;
-        a.lpe = (p.S >= 32 && tot * 64 < (1ll << 31)) ? 64 : 1;
-        hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((tot * a.lpe + 255) / 256)), dim3(256), 0, st, a);
+        static const bool old_reduce = getenv("DCV_CL_OLD_WGRAD_REDUCE") != nullptr;      // A/B only
+        const int64_t nel = (int64_t)p.tiles * (128 * 128);
+        if (old_reduce) {
+            a.lpe = (p.S >= 32 && tot * 64 < (1ll << 31)) ? 64 : 1;
+            hipLaunchKernelGGL(cl_wgrad_reduce_kernel, dim3((unsigned)((tot * a.lpe + 255) / 256)), dim3(256), 0, st, a);
+        } else if (p.S >= 64) {
+            hipLaunchKernelGGL((cl_wgrad_reduce_slab_kernel<16, 16>), dim3((unsigned)((nel + 15) / 16)), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((cl_wgrad_reduce_slab_kernel<64, 4>), dim3((unsigned)((nel + 63) / 64)), dim3(256), 0, st, a);
+        }
         DCV_LAUNCH_CHECK();
     }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, bf16 channels-last)", p.tiles, p.S);
