@@ -26,4 +26,20 @@ for f in conv_mfma elementwise conv_cl16 cl_elementwise; do
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/conv_mfma.o" "$OBJ/elementwise.o" "$OBJ/conv_cl16.o" "$OBJ/cl_elementwise.o"
+# The flag above is only worth something if it took effect (its "not a recognized feature" host-pass message is filtered, and a hipcc that dropped or renamed
+# the feature would bring the packed instructions back silently): disassemble the device code of the library just linked and fail on any packed-FP32 arithmetic.
+OBJDUMP=/opt/rocm/lib/llvm/bin/llvm-objdump
+if [ -z "${DCV_PACKED_FP32:-}" ] && [ -x "$OBJDUMP" ]; then
+  TMPD="$(mktemp -d)"; cp "$OUT" "$TMPD/lib.so"
+  ( cd "$TMPD" && "$OBJDUMP" --offloading lib.so > /dev/null 2>&1 )
+  n=0; found=0
+  for co in "$TMPD"/lib.so.*gfx950*; do
+    [ -f "$co" ] || continue
+    n=$((n + 1))
+    if "$OBJDUMP" -d --mcpu=gfx950 "$co" | grep -E -m 5 "v_pk_(fma|mul|add)_f32"; then found=1; fi
+  done
+  rm -rf "$TMPD"
+  [ "$n" -gt 0 ] || { echo "build.sh: could not extract the gfx950 code object from $OUT to check it" >&2; exit 1; }
+  [ "$found" -eq 0 ] || { echo "build.sh: packed-FP32 arithmetic (v_pk_*_f32) in the device code although DCV_PACKED_FP32 is unset: the -packed-fp32-ops target feature did not take effect" >&2; rm -f "$OUT"; exit 1; }
+fi
 echo "built $OUT"

@@ -154,13 +154,19 @@ __device__ __forceinline__ uint32_t cl_dim_mask(const ClDim& t, int o) {
 // positions, K step 32.  LDS: two stages of [BM rows][64 B] activations + [BN rows][64 B] weights; the four 16-byte chunks of a
 // row are XOR-swizzled with (row >> 2) & 3 on the DMA's SOURCE side (an LDS-DMA lands lane-linear), which makes the fragment
 // reads "32 rows x one chunk" (ds_read_b128) conflict-free.
-template <int TOC, int TM, int WOC, int WM, bool THIN>
+template <int N>
+__device__ __forceinline__ void cl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NS = LDS stages: the DMAs of K step st + NS - 1 are issued at the top of step st (NS = 2: one step ahead, four workgroups per CU; NS = 3: two steps
+// ahead behind a counted vmcnt wait, three workgroups per CU)
+template <int TOC, int TM, int WOC, int WM, bool THIN, int NS>
 __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pack) {
     constexpr int BN = 32 * TOC * WOC, BM = 32 * TM * WM;
     constexpr int XPT = BM * 4 / 256, WPT = (BN * 4 + 255) / 256;
     constexpr int XB = BM * 64, WB = BN * 64, STAGE = XB + WB;
     static_assert(WOC * WM == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + (THIN ? 256 : 0)];
+    static_assert(NS >= 2 && NS <= 4, "2-4 stages");
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + (THIN ? 256 : 0)];
 
     // workgroup -> (class, oc tile, m tile): ids 8 apart (the same XCD's L2) share the gathered operand
     const unsigned grp = (unsigned)(pack.tiles_oc * pack.ncls), loc = blockIdx.x >> 3;
@@ -180,9 +186,9 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 0x80000000u, 0x00020000);
     // thin operands: a lane's granule is one TAP of the step, so the tap offset is per lane: table in LDS (one array: see the LDS-DMA tracking
     // note in conv_mfma.hip), read one step ahead of its use
-    const int32_t* toff_l = reinterpret_cast<const int32_t*>(smem + 2 * STAGE);
+    const int32_t* toff_l = reinterpret_cast<const int32_t*>(smem + NS * STAGE);
     if constexpr (THIN) {
-        if (tid < 64) reinterpret_cast<int32_t*>(smem + 2 * STAGE)[tid] = a.toff[tid];
+        if (tid < 64) reinterpret_cast<int32_t*>(smem + NS * STAGE)[tid] = a.toff[tid];
         __syncthreads();
     }
 
@@ -283,13 +289,27 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
         }
 
     const int nst = a.nsteps;
+    // vector-memory instructions one K step costs THIS wave (the weight tile of a 32-channel tile is 128 granules: waves 0-1 only)
+    const bool wfull = (BN * 4) % 256 == 0 || wave * 64 + 256 * (WPT - 1) < BN * 4;
     CL_ISSUE(0, 0)
+    if constexpr (NS >= 3) { if (nst > 1) CL_ISSUE(1, 1) }
+    if constexpr (NS >= 4) { if (nst > 2) CL_ISSUE(2, 2) }
+    int buf = 0;
+    [[maybe_unused]] int nbuf = NS - 1;      // stage of step st; stage the step issued now lands in
     for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // step st's granules have landed: all but the (NS - 2) younger steps' instructions of this wave are done
+        if constexpr (NS == 2) cl_wait_vm<0>();
+        else {
+            const int ahead = min(NS - 2, nst - 1 - st);
+            if (ahead == 0) cl_wait_vm<0>();
+            else if (ahead == 1) { if (wfull) cl_wait_vm<XPT + WPT>(); else cl_wait_vm<XPT + WPT - 1>(); }
+            else { if (wfull) cl_wait_vm<2 * (XPT + WPT)>(); else cl_wait_vm<2 * (XPT + WPT - 1)>(); }
+        }
         __syncthreads();
-        if (st + 1 < nst) CL_ISSUE(st + 1, buf ^ 1)
+        if (st + NS - 1 < nst) CL_ISSUE(st + NS - 1, nbuf)
         const char* sb = smem + buf * STAGE;
+        nbuf = buf;
+        buf = buf + 1 == NS ? 0 : buf + 1;
         bf16x8 a8[TOC][2], b8[TM][2];
 #pragma unroll
         for (int i = 0; i < TOC; ++i)
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 32 + l31;
         uint32_t vo = 0xffffffffu;
-        if (m < a.M) {
+        if (m < a.M && !(a.pad2 & 1)) {
             const uint32_t n = fdiv((uint32_t)m, a.div_sp);
             uint32_t r = (uint32_t)m - n * a.div_sp.div;
             const uint32_t od = fdiv(r, a.div_hw);
@@ -467,6 +487,8 @@ struct ClWgradArgs {
     int32_t g_cbytes, T;         // same for the gathered tensor; taps
     int32_t tiles_d, gblocks;    // dense-channel tiles; 128-channel blocks of the gathered tensor (1 when GCp <= 128)
     int32_t gcb8, ntpt;          // 16-byte chunks per tap in a tile (GCB / 8); taps per tile (128 / GCB)
+    int32_t tiles, S;            // tiles_d x tiles_j; position splits
+    int32_t xcd_map, pad0;
     uint32_t d_bytes, g_bytes;
     int32_t toff[64];            // byte offset of tap t relative to a position's gbase
 };
@@ -479,9 +501,25 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wd = wave >> 1, wj = wave & 1;
-    const int d_t = blockIdx.x % a.tiles_d, j_t = blockIdx.x / a.tiles_d;
+    // workgroup -> (tile, position split): ids 8 apart run on one XCD.  The (split, tile) pairs in split-major order are cut into 8 contiguous, equally long
+    // ranges, one per XCD: the workgroups an XCD runs at any time are then the tiles of one or a few position splits — they read the same dense rows and
+    // overlapping gathered rows, so its L2 serves every tile after the first — and every XCD gets the same number of workgroups whatever the split count
+    // (first form, splits dealt out whole: 5 of 8 XCDs idle at 3 splits, 2:1 imbalance at 12).  DCV_CL_WGRAD_FLAT: tile-major ids, round-robin (A/B)
+    int tile_id, split;
+    if (a.xcd_map) {
+        const unsigned W = (unsigned)a.tiles * (unsigned)a.S, q = W >> 3, r = W & 7u;
+        const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const unsigned item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        tile_id = (int)(item % (unsigned)a.tiles);
+        split = (int)(item / (unsigned)a.tiles);
+    } else {
+        tile_id = (int)(blockIdx.x % (unsigned)a.tiles);
+        split = (int)(blockIdx.x / (unsigned)a.tiles);
+    }
+    if (split >= a.S) return;
+    const int d_t = tile_id % a.tiles_d, j_t = tile_id / a.tiles_d;
     const int tg = j_t / a.gblocks, gb = j_t - tg * a.gblocks;
-    const int m_begin = blockIdx.y * a.chunk;
+    const int m_begin = split * a.chunk;
     const int m_end = min(a.M, m_begin + a.chunk);
     const int nst = m_end > m_begin ? (m_end - m_begin + 31) / 32 : 0;
 
@@ -591,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
             e0 = n0; e1 = n1;
         }
     }
-    float* __restrict__ out = a.slab + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
+    float* __restrict__ out = a.slab + ((int64_t)split * a.tiles + tile_id) * (128 * 128);
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -821,10 +859,13 @@ static int64_t cl_extent_bytes(const dcv_dims5& d, int cpad) {
     return 2 * ((int64_t)(d.n - 1) * d.sn + (int64_t)(d.d - 1) * d.sd + (int64_t)(d.h - 1) * d.sh + (int64_t)(d.w - 1) * d.sw + cpad);
 }
 
+// (Round 5, measured and not instantiated: NS = 3 and 4 — two / three K steps in flight behind counted vmcnt waits, at 3 or 2 workgroups per CU instead of 4 —
+// ran the surreal-depth1 layer table in 39.5 / 41.3 ms against 37.9 and the iteration in 49.3 / 51.4 ms against 47.2 (profiles/r05_ab_cl16.txt): what bounds the
+// loop is the issue cost of the LDS-DMA instructions, 4-5 per wave and K step against 8 MFMAs, not the distance of the prefetch; fewer waves per SIMD lose more.)
 template <int TOC, int TM, int WOC, int WM>
 static void cl_launch_gather(const ClGatherPack& pk, bool thin, dim3 grid, hipStream_t s) {
-    if (thin) hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, true>), grid, dim3(256), 0, s, pk);
-    else hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, false>), grid, dim3(256), 0, s, pk);
+    if (thin) hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, true, 2>), grid, dim3(256), 0, s, pk);
+    else hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, false, 2>), grid, dim3(256), 0, s, pk);
 }
 
 
@@ -836,6 +877,7 @@ struct ClTabKey {
 };
 static std::mutex g_tab_mu;
 static std::map<ClTabKey, ClPosEntry*> g_tabs;
+static constexpr size_t CL_TAB_CACHE_MAX = 256;
 
 static bool cl_pixel_linear(const dcv_dims5& d, int64_t* pitch) {
     int64_t p = 0;
@@ -1093,6 +1135,8 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
             if (pitch) *pitch = OCp;
         }
     }
+    static const int dbg = getenv("DCV_CL_DEBUG") ? atoi(getenv("DCV_CL_DEBUG")) : 0;      // 1: no epilogue stores (timing experiments only)
+    for (int i = 0; i < n; ++i) pk.c[i].pad2 = dbg;
     for (int i = n; i < 4; ++i) pk.c[i] = pk.c[0];
     pk.ncls = n; pk.tiles_oc = OCp / tc.bn; pk.tiles_m = (int)maxtm;
     const dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
@@ -1165,21 +1209,28 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
     hipStream_t st = static_cast<hipStream_t>(stream);
     ClPosEntry* tab = static_cast<ClPosEntry*>(ws);
     float* slab = reinterpret_cast<float*>(static_cast<char*>(ws) + p.tab_bytes);
-    bool build = true;
+    // A kept table is published (inserted into g_tabs) only AFTER its build kernel has been launched and has completed: a second host thread with the same
+    // key either finds a complete table or builds its own (the loser of the insert frees its copy); a failed launch / synchronise frees the copy and leaves
+    // no entry behind.  The cache is bounded (CL_TAB_CACHE_MAX keys: the three GPU configs hold ~30 each); past the bound a call builds into its workspace.
+    bool build = true, keep = false;
     static const bool no_cache = getenv("DCV_CL_NO_POSTAB_CACHE") != nullptr;
+    ClTabKey key;
+    memset(&key, 0, sizeof(key));
     if (!no_cache) {
-        ClTabKey key;
-        memset(&key, 0, sizeof(key));
         DCV_HIP_CHECK(hipGetDevice(&key.dev));
         const int32_t v[24] = {g->kd, g->kh, g->kw, g->sd, g->sh, g->sw, g->pd, g->ph, g->pw, D.n, D.d, D.h, D.w, G.d, G.h, G.w, (int32_t)G.sd, (int32_t)G.sh, (int32_t)G.sw, 0, 0, 0, 0, 0};
         memcpy(key.v, v, sizeof(v));
         key.w[0] = G.sn;
-        std::lock_guard<std::mutex> lk(g_tab_mu);
-        auto it = g_tabs.find(key);
-        if (it != g_tabs.end()) { tab = it->second; build = false; }
-        else {
+        bool room = false;
+        {
+            std::lock_guard<std::mutex> lk(g_tab_mu);
+            auto it = g_tabs.find(key);
+            if (it != g_tabs.end()) { tab = it->second; build = false; }
+            else room = g_tabs.size() < CL_TAB_CACHE_MAX;
+        }
+        if (build && room) {
             ClPosEntry* dev_tab = nullptr;
-            if (hipMalloc(reinterpret_cast<void**>(&dev_tab), p.tab_bytes) == hipSuccess) { g_tabs[key] = dev_tab; tab = dev_tab; }
+            if (hipMalloc(reinterpret_cast<void**>(&dev_tab), p.tab_bytes) == hipSuccess) { tab = dev_tab; keep = true; }
             else (void)hipGetLastError();      // no memory for a kept copy: this call builds into the workspace
         }
     }
@@ -1192,9 +1243,19 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
         a.gext[0] = G.d; a.gext[1] = G.h; a.gext[2] = G.w;
         a.g_sn = G.sn; a.g_sd = (int32_t)G.sd; a.g_sh = (int32_t)G.sh; a.g_sw = (int32_t)G.sw;
         hipLaunchKernelGGL(cl_postab_kernel, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, a);
-        DCV_LAUNCH_CHECK();
-        // a kept table is read by later calls on OTHER streams (the discriminators' lanes): it must be complete before this call returns (once per layer)
-        if (tab != static_cast<ClPosEntry*>(ws)) DCV_HIP_CHECK(hipStreamSynchronize(st));
+        g_launches.fetch_add(1, std::memory_order_relaxed);
+        hipError_t e = hipGetLastError();
+        // a kept table is read by later calls on OTHER streams (the discriminators' lanes): it must be complete before it is published (once per layer)
+        if (e == hipSuccess && keep) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            if (keep) (void)hipFree(tab);
+            return fail(DCV_EHIP, "cl wgrad: building the position table failed: %s", hipGetErrorString(e));
+        }
+        if (keep) {
+            std::lock_guard<std::mutex> lk(g_tab_mu);
+            auto ins = g_tabs.emplace(key, tab);
+            if (!ins.second) { (void)hipFree(tab); tab = ins.first->second; }      // another thread published the same table meanwhile: use that one
+        }
     }
     {
         ClWgradArgs a;
@@ -1208,7 +1269,9 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
             const int kd = t / (g->kh * g->kw), kh = (t / g->kw) % g->kh, kw = t % g->kw;
             a.toff[t] = (int32_t)(2 * ((int64_t)kd * G.sd + (int64_t)kh * G.sh + (int64_t)kw * G.sw));
         }
-        hipLaunchKernelGGL(cl_wgrad_kernel, dim3((unsigned)p.tiles, (unsigned)p.S), dim3(256), 0, st, a);
+        static const bool flat = getenv("DCV_CL_WGRAD_FLAT") != nullptr;      // A/B only
+        a.tiles = p.tiles; a.S = p.S; a.xcd_map = flat ? 0 : 1;
+        hipLaunchKernelGGL(cl_wgrad_kernel, dim3((unsigned)(p.tiles * p.S)), dim3(256), 0, st, a);
         DCV_LAUNCH_CHECK();
     }
     {

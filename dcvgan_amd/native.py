@@ -166,14 +166,17 @@ def set_precision(mode: str):
     check(lib().dcv_set_precision({"fp32": 0, "bf16": 1, "f32x6": 2}[mode]), "dcv_set_precision")
 
 
-def csrc_digest() -> str:
+def csrc_digest(cl: bool = False) -> str:
     """sha256 over the sources of the fp32 kernels the headline benchmark runs (csrc/conv_mfma.hip, elementwise.hip, dcv_common.h, build.sh).
     Profiles committed under profiles/ carry it, so a number measured on other kernels is never attached to this build (bench.py).  (The bf16
     channels-last path's sources — conv_cl16.hip, cl_elementwise.hip — are separate translation units and not part of it.)"""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
-    for f in ("conv_mfma.hip", "elementwise.hip", "dcv_common.h", "build.sh"):
+    files = ("conv_mfma.hip", "elementwise.hip", "dcv_common.h", "build.sh")
+    if cl:      # the bf16 channels-last path: its own translation units on top (profiles of that path carry this digest)
+        files += ("conv_cl16.hip", "cl_elementwise.hip")
+    for f in files:
         h.update(f.encode() + b"\0")
         h.update(open(os.path.join(src, f), "rb").read())
     return h.hexdigest()
