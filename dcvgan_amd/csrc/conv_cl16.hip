@@ -104,7 +104,7 @@ struct ClGatherArgs {
     const __bf16* wp;            // [step][OCp][32] bf16
     int32_t M, OCp, nsteps, T;   // positions, padded output channels (multiple of the tile's), 32-deep K steps, taps
     int32_t cblk, y_c;           // 32-channel blocks per tap (0 = thin); channels to store (destination channels, multiple of 4)
-    int32_t x_cmax, pad0;        // bytes of one pixel's own channels, rounded up to a granule (granules past them read as zeros)
+    int32_t x_cmax, coalesce;    // bytes of one pixel's own channels, rounded up to a granule (granules past them read as zeros); epilogue through LDS (16-byte row-order stores)
     FastDiv div_sp, div_hw, div_w;
     ClDim td, th, tw;
     int64_t x_sn, y_sn;          // element strides
@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
     constexpr int XB = BM * 64, WB = BN * 64, STAGE = XB + WB;
     static_assert(WOC * WM == 4, "4 waves");
     static_assert(NS >= 2 && NS <= 4, "2-4 stages");
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE + (THIN ? 256 : 0)];
+    // epilogue image: the tile as [position][BN channels] bf16, pitch BN * 2 + 16 bytes, + one byte offset per position row
+    constexpr int EPITCH = BN * 2 + 16, EPI = BM * EPITCH + BM * 4;
+    constexpr int SMEM = (NS * STAGE + (THIN ? 256 : 0)) > EPI ? (NS * STAGE + (THIN ? 256 : 0)) : EPI;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     // workgroup -> (class, oc tile, m tile): ids 8 apart (the same XCD's L2) share the gathered operand
     const unsigned grp = (unsigned)(pack.tiles_oc * pack.ncls), loc = blockIdx.x >> 3;
@@ -329,11 +332,64 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
         __builtin_amdgcn_s_setprio(0);
     }
 
-    // ---- epilogue: 4 consecutive output channels of one position per register quad -> one 8-byte store
+    // ---- epilogue
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
     const int act = a.act;
     const float slope = a.slope;
     const bool accum = a.accumulate != 0;
+    if (a.coalesce) {
+        // Through LDS: an accumulator register quad is 4 channels of ONE position, so direct stores are 8-byte pieces of 32 different pixels per wave
+        // instruction (16 or 32 bytes of a 128- / 256-byte line at a time; round 5: the direct epilogue cost 2.4 ms of the 26 ms of gather kernels).  The
+        // tile goes to LDS as [position][channel] instead and leaves as 16-byte granules in row order: a wave instruction writes 1 KB = whole lines of
+        // 4-16 consecutive positions.  (Not for accumulate: the old value would have to be added after the bf16 rounding.)
+        __syncthreads();                                     // every wave has left the K loop: the stage buffers are free
+        uint32_t* rowoff = reinterpret_cast<uint32_t*>(smem + BM * EPITCH);
+        if (tid < BM) {
+            const int m = m0 + tid;
+            uint32_t vo = 0xffffffffu;
+            if (m < a.M && !(a.pad2 & 1)) {
+                const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+                uint32_t r = (uint32_t)m - n * a.div_sp.div;
+                const uint32_t od = fdiv(r, a.div_hw);
+                r -= od * a.div_hw.div;
+                const uint32_t oh = fdiv(r, a.div_w);
+                const uint32_t ow = r - oh * a.div_w.div;
+                vo = (uint32_t)(2 * ((int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw + a.y_off));
+            }
+            rowoff[tid] = vo;
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int row = (wm * TM + j) * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ocl = (woc * TOC + i) * 32 + 8 * q + 4 * lhi;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = cl_act(acc[i][j][4 * q + e], act, slope);
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
+                    u32x2 o;
+                    o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
+                    o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                    *reinterpret_cast<u32x2*>(smem + row * EPITCH + ocl * 2) = o;
+                }
+        }
+        __syncthreads();
+        constexpr int GPR = BN / 8;                          // 16-byte granules per position row
+#pragma unroll
+        for (int s = 0; s < BM * GPR / 256; ++s) {
+            const int idx = tid + 256 * s, row = idx / GPR, c = idx % GPR;
+            const uint32_t vo = rowoff[row];
+            const int oc = oc0 + 8 * c;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * EPITCH + c * 16);
+            const uint32_t v2 = (vo != 0xffffffffu && oc < a.y_c) ? vo + (uint32_t)(2 * oc) : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(v, yrs, v2, 0, 0);
+        }
+    } else {
+    // direct: 4 consecutive output channels of one position per register quad -> one 8-byte store
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + (wm * TM + j) * 32 + l31;
@@ -370,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
                 o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
                 __builtin_amdgcn_raw_buffer_store_b64(o, yrs, v2, 0, 0);
             }
+    }
     }
     if (a.stat) {
         // conv -> BatchNorm pairs: {sum, sum of squares} of this tile's STORED values (the bf16 roundings, as the BatchNorm op's own pass would read them), per channel.
@@ -1015,7 +1072,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     memset(&pk, 0, sizeof(pk));
     ClGatherArgs& a = pk.c[0];
     a.x = static_cast<const __bf16*>(src_p); a.y = static_cast<__bf16*>(ws); a.wp = static_cast<const __bf16*>(packed);
-    a.M = (int)Msrc; a.OCp = OCgp; a.T = 1; a.cblk = Cp / 32; a.nsteps = Cp / 32; a.y_c = (OCg + 3) / 4 * 4; a.x_cmax = 2 * pad8(pl.RC);
+    a.M = (int)Msrc; a.OCp = OCgp; a.T = 1; a.cblk = Cp / 32; a.nsteps = Cp / 32; a.y_c = pad8(OCg); a.x_cmax = 2 * pad8(pl.RC);      // Z owns its pixels (pitch zp >= pad8): whole 8-column groups, zeros past OCg
     a.div_sp = make_fastdiv((uint32_t)(src.d * src.h * src.w)); a.div_hw = make_fastdiv((uint32_t)(src.h * src.w)); a.div_w = make_fastdiv((uint32_t)src.w);
     ClDim one;
     memset(&one, 0, sizeof(one));
@@ -1024,6 +1081,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     a.x_sn = src.sn; a.x_sd = (int32_t)src.sd; a.x_sh = (int32_t)src.sh; a.x_sw = (int32_t)src.sw;
     a.y_sn = (int64_t)src.d * src.h * src.w * zp; a.y_sd = src.h * src.w * zp; a.y_sh = src.w * zp; a.y_sw = zp; a.y_off = 0;
     a.act = DCV_ACT_NONE; a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)zbytes;
+    a.coalesce = (a.y_c % 8 == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && !getenv("DCV_CL_DIRECT_EPILOGUE")) ? 1 : 0;
     for (int i = 1; i < 4; ++i) pk.c[i] = pk.c[0];
     pk.ncls = 1; pk.tiles_oc = OCgp / tc.bn; pk.tiles_m = (int)((Msrc + tc.bm - 1) / tc.bm);
     const dim3 grid((unsigned)((pk.tiles_m + 7) / 8 * 8 * pk.tiles_oc));
@@ -1114,6 +1172,9 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
         a.y_sd = (int32_t)(dst.sd * c.out_mul[0]); a.y_sh = (int32_t)(dst.sh * c.out_mul[1]); a.y_sw = (int32_t)(dst.sw * c.out_mul[2]);
         a.y_off = (int32_t)(dst.sd * c.out_off[0] + dst.sh * c.out_off[1] + dst.sw * c.out_off[2]);
         a.act = act; a.slope = slope; a.accumulate = accumulate;
+        // 16-byte row-order stores need whole 8-channel groups at 16-byte-aligned pixel bases (pitches are multiples of 8 elements: cl_check_tensor)
+        static const bool no_coalesce = getenv("DCV_CL_DIRECT_EPILOGUE") != nullptr;      // A/B only
+        a.coalesce = (!accumulate && ocs % 8 == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && !no_coalesce) ? 1 : 0;
         a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
         for (int t = 0; t < T; ++t) {
             const int ud = t / (c.t[1].n * c.t[2].n), uh = (t / c.t[2].n) % c.t[1].n, uw = t % c.t[2].n;
