@@ -849,6 +849,143 @@ __global__ __launch_bounds__(256) void cl_col2im_kernel(const ClCol2imArgs a) {
     *reinterpret_cast<u32x4*>(yp) = o4;
 }
 
+
+// --------------------------------------------------------------------------- //
+// Thin destination, fused (round 5): the 3x3 / stride 1 / pad 1 scatter-form ops into <= 3 channels on 64-wide rows — the colour generator's RGB head forward
+// (128 -> 3, tanh; generator.py:273-276) and its stem's data gradient (64 -> 1; generator.py:204-211).  The GEMM + col2im form above writes and re-reads a Z tensor
+// of 32 columns per SOURCE pixel and stages the source through the tiled gather kernel: 0.93 ms for the 1.68 GB source of the RGB head.  Here the source is read
+// ONCE, in whole pixels, and nothing but the thin result is written:
+//   a workgroup owns a band of 16 destination rows of one image; its four waves each take 32 consecutive source pixels (half a row) per round: the pixels'
+//   channels arrive by LDS-DMA as whole 16-byte-granule runs (a wave instruction = 1 KB = 4-16 whole pixels; the granules of a pixel XOR-swizzled on the source
+//   side so that the "32 pixels x one granule" fragment reads are conflict-free), three units in flight per wave, no workgroup barrier on that path;
+//   Z[pixel][tap, oc] = X W comes out of the MFMAs (weights held in registers: the packed thin format of cl_pack_thin_kernel) and goes to a ring of six Z rows in
+//   LDS (fp32, zero columns left and right); after one barrier per round two destination rows gather their 9 x OC values from the ring, apply the activation and
+//   leave as 16-byte pixels.  Bands of one image sit on one XCD (ids 8 apart), so the two halo rows a band re-reads come from its L2.
+// Roofline: HBM (source once + destination once).
+// --------------------------------------------------------------------------- //
+struct ClThin3Args {
+    const __bf16* x; __bf16* y; const __bf16* wp;
+    int32_t N, H, OC, act;
+    int32_t pad0, bands;            // bands of 16 rows per image
+    float slope; int32_t pad;
+    int64_t x_sn, y_sn;             // element strides
+    int32_t x_sh, x_sw, y_sh, y_sw;
+    uint32_t x_bytes, y_bytes;
+};
+template <int CPX>      // 16-byte granules per source pixel = C / 8: 4, 8 or 16
+__global__ __launch_bounds__(256) void cl_thin3x3_kernel(const ClThin3Args a) {
+    constexpr int W = 64, UNIT = 32 * CPX * 16, NBUF = 3, PPU = CPX / 2, STEPS = CPX / 4;
+    constexpr int ZP = 36, ZROW = (W + 2) * ZP, RING = 6;            // floats
+    constexpr int SH = CPX == 16 ? 0 : (CPX == 8 ? 1 : 2), MASK = CPX == 16 ? 15 : CPX - 1;
+    __shared__ __attribute__((aligned(16))) char smem[4 * NBUF * UNIT + RING * ZROW * 4];
+    float* zring = reinterpret_cast<float*>(smem + 4 * NBUF * UNIT);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // workgroup -> (image, band): the bands of an image take consecutive slots of one XCD
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const int img = (int)((slot / (unsigned)a.bands) * 8u + xcd), band = (int)(slot % (unsigned)a.bands);
+    if (img >= a.N) return;
+    const int b0 = band * 16, zr0 = b0 - 1;
+
+    for (int i = tid; i < RING * ZROW; i += 256) zring[i] = 0.f;      // zero columns (and rows nobody has written yet)
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    // weights: A fragments of all K steps in registers
+    bf16x8 wfrag[STEPS][2];
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wfrag[st][h] = *reinterpret_cast<const bf16x8*>(a.wp + ((st * 32 + l31) * 32 + (2 * h + lhi) * 8));
+    // staging roles: granule gi = i * 64 + lane of the unit -> pixel gi / CPX, physical granule gi % CPX holding logical granule ^ swz(pixel)
+    uint32_t voff[PPU];
+#pragma unroll
+    for (int i = 0; i < PPU; ++i) {
+        const int gi = i * 64 + lane, px = gi / CPX, pg = gi % CPX;
+        voff[i] = (uint32_t)(px * a.x_sw * 2 + ((pg ^ ((px >> SH) & MASK)) << 4));
+    }
+    char* xbuf = smem + wave * (NBUF * UNIT);
+    const int half = wave & 1, wrow = wave >> 1;
+    const int64_t img_base = (int64_t)img * a.x_sn * 2;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define T3_ISSUE(ROUND, BUF)                                                                                                   \
+    {                                                                                                                          \
+        const int zr_ = zr0 + 2 * (ROUND) + wrow;                                                                              \
+        const bool ok_ = zr_ >= 0 && zr_ < a.H;                                                                                \
+        const uint32_t so_ = ok_ ? (uint32_t)(img_base + ((int64_t)zr_ * a.x_sh + (int64_t)half * 32 * a.x_sw) * 2) : 0u;     \
+        _Pragma("unroll") for (int i = 0; i < PPU; ++i)                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xbuf + (BUF) * UNIT + i * 1024), 16, ok_ ? voff[i] : 0xffffffffu, so_, 0, 0); \
+    }
+#else
+#define T3_ISSUE(ROUND, BUF) { (void)xrs; (void)voff; (void)img_base; }
+#endif
+    constexpr int ROUNDS = 9;      // Z rows b0 - 1 .. b0 + 16
+    T3_ISSUE(0, 0)
+    T3_ISSUE(1, 1)
+    __syncthreads();               // ring zeroed
+    int buf = 0;
+    for (int t = 0; t < ROUNDS; ++t) {
+        if (t + 2 < ROUNDS) { T3_ISSUE(t + 2, (buf + 2) % NBUF) cl_wait_vm<2 * PPU>(); }
+        else if (t + 1 < ROUNDS) cl_wait_vm<PPU>();
+        else cl_wait_vm<0>();
+        // Z of this wave's 32 pixels: 32 columns x 32 pixels
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* xb = xbuf + buf * UNIT;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int lg = st * 4 + 2 * h + lhi;
+                const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(xb + l31 * (CPX * 16) + ((lg ^ ((l31 >> SH) & MASK)) << 4));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[st][h], b8, acc, 0, 0, 0);
+            }
+        {
+            const int zr = zr0 + 2 * t + wrow;
+            float* zp = zring + ((zr - zr0) % RING) * ZROW + (1 + half * 32 + l31) * ZP;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(zp + 8 * q + 4 * lhi) = v;
+            }
+        }
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+        __syncthreads();
+        // destination rows zr0 + 2 t - 1 and zr0 + 2 t: out[o][c][oc] = sum_{dr, dc} Z[o + dr][c + dc][((1 - dr) * 3 + (1 - dc)) * OC + oc]
+        if (tid < 128) {
+            const int o = zr0 + 2 * t - 1 + (tid >> 6), c = tid & 63;
+            if (o >= b0 && o < b0 + 16 && o < a.H) {
+                float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dr = -1; dr <= 1; ++dr) {
+                    const float* zrow = zring + ((o + dr - zr0) % RING) * ZROW + (1 + c) * ZP;
+#pragma unroll
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const float* zq = zrow + dc * ZP + ((1 - dr) * 3 + (1 - dc)) * a.OC;
+#pragma unroll
+                        for (int oc = 0; oc < 3; ++oc) r[oc] += oc < a.OC ? zq[oc] : 0.f;
+                    }
+                }
+                const uint32_t vo = (uint32_t)(2 * ((int64_t)img * a.y_sn + (int64_t)o * a.y_sh + (int64_t)c * a.y_sw));
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = e < a.OC ? cl_act(r[e], a.act, a.slope) : 0.f;
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                u32x4 o4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; o4[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2)); }
+                __builtin_amdgcn_raw_buffer_store_b128(o4, yrs, vo, 0, 0);
+            }
+        }
+    }
+#undef T3_ISSUE
+}
+
 struct ClTile { int bn, bm; };
 static ClTile cl_pick_tile(int OC) {
     if (OC > 64) return {128, 128};
@@ -1065,6 +1202,32 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     if (dst.w > 1 && dst.sw < 8) return fail(DCV_EINVAL, "cl conv: thin destination needs a pixel pitch of 8");
     const int64_t xb = cl_extent_bytes(src, Cp);
     if (xb >= (1ll << 31) || zbytes >= (1ull << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: tensors beyond 2 GB");
+    {
+        // fused form (cl_thin3x3_kernel): 2-D 3x3 / stride 1 / pad 1 scatter-form, 64-wide rows, rows in bands of 16, 32 / 64 / 128 source channels, <= 3 destination channels
+        static const bool no_fused = getenv("DCV_CL_NO_THIN3") != nullptr;      // A/B only
+        const bool direct3 = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
+        const int C3 = pl.RC;
+        if (!no_fused && !accumulate && !direct3 && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
+            src.d == 1 && dst.d == 1 && src.w == 64 && src.h % 16 == 0 && dst.w == 64 && dst.h == src.h && pl.OC <= 3 && (C3 == 32 || C3 == 64 || C3 == 128) &&
+            (reinterpret_cast<uintptr_t>(src_p) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && dst.sw >= 8 && src.sw >= C3) {
+            const int64_t xb3 = cl_extent_bytes(src, C3), yb3 = cl_extent_bytes(dst, 8);
+            if (xb3 < (1ll << 31) && yb3 < (1ll << 31)) {
+                ClThin3Args t;
+                memset(&t, 0, sizeof(t));
+                t.x = static_cast<const __bf16*>(src_p); t.y = static_cast<__bf16*>(dst_p); t.wp = static_cast<const __bf16*>(packed);
+                t.N = src.n; t.H = src.h; t.OC = pl.OC; t.act = act; t.bands = src.h / 16; t.slope = slope;
+                t.x_sn = src.sn; t.y_sn = dst.sn; t.x_sh = (int32_t)src.sh; t.x_sw = (int32_t)src.sw; t.y_sh = (int32_t)dst.sh; t.y_sw = (int32_t)dst.sw;
+                t.x_bytes = (uint32_t)xb3; t.y_bytes = (uint32_t)yb3;
+                const unsigned nwg = (unsigned)((src.n + 7) / 8 * 8 * t.bands);
+                if (C3 == 128) hipLaunchKernelGGL((cl_thin3x3_kernel<16>), dim3(nwg), dim3(256), 0, st, t);
+                else if (C3 == 64) hipLaunchKernelGGL((cl_thin3x3_kernel<8>), dim3(nwg), dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((cl_thin3x3_kernel<4>), dim3(nwg), dim3(256), 0, st, t);
+                snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_thin3x3_kernel<%d> (fused GEMM + tap gather, thin destination, bf16 channels-last)", C3 / 8);
+                DCV_LAUNCH_CHECK();
+                return DCV_OK;
+            }
+        }
+    }
     const ClTile tc = cl_pick_tile(OCg);
     const int OCgp = (OCg + tc.bn - 1) / tc.bn * tc.bn;
     // (1) Z = X (1x1) Wg : every source pixel once

@@ -34,6 +34,9 @@ CASES = [
     ("convT2d_4s1p0_latent", True, 2, 50, 128, 4, 1, 0, (1, 1), 9),
     ("convT2d_4s2p1_96_1", True, 2, 96, 1, 4, 2, 1, (32, 32), 2),
     ("convT2d_3s1p1_128_3", True, 2, 128, 3, 3, 1, 1, (64, 64), 2),
+    ("convT2d_3s1p1_128_3_n9", True, 2, 128, 3, 3, 1, 1, (64, 64), 9),       # fused thin-destination kernel: images past a multiple of 8 (XCD slots without an image)
+    ("convT2d_3s1p1_32_2", True, 2, 32, 2, 3, 1, 1, (64, 64), 3),            # its 32-channel instance
+    ("convT2d_3s1p1_64_1_h32", True, 2, 64, 1, 3, 1, 1, (32, 64), 2),        # its 64-channel instance, two bands per image
     ("conv3d_4s122_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2),
     ("conv3d_4s122_thin3_32", False, 3, 3, 32, 4, (1, 2, 2), (0, 1, 1), (16, 64, 64), 1),
     ("conv3d_4s122_thin1_32", False, 3, 1, 32, 4, (1, 2, 2), (0, 1, 1), (15, 64, 64), 1),
@@ -82,7 +85,10 @@ def test_conv_cl16(case):
     xc.requires_grad_(True)
     wd = w.detach().to(DEV).requires_grad_(True)
     y = ops_cl.conv(xc, wd, ops.conv_geom(wd, s_t, p_t, tr))
-    assert y.dtype == torch.bfloat16 and "cl_gather" in native.lib().dcv_debug_last_kernel().decode()
+    kn = native.lib().dcv_debug_last_kernel().decode()
+    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn), kn
+    if name.startswith("convT2d_3s1p1"):
+        assert "cl_thin3x3" in kn, kn           # the fused thin-destination form is the one these shapes select
     cc, cstore, G2 = guarded_cl(cot.shape, cot.to(DEV))
     gx, gw = torch.autograd.grad(y, [xc, wd], cc)
     torch.cuda.synchronize()
