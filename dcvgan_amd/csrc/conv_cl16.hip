@@ -986,6 +986,110 @@ __global__ __launch_bounds__(256) void cl_thin3x3_kernel(const ClThin3Args a) {
 #undef T3_ISSUE
 }
 
+
+// --------------------------------------------------------------------------- //
+// Thin source, fused (round 5): the 3x3 / stride 1 / pad 1 direct-form ops out of <= 8 channels on 64-wide rows — the colour generator's stem forward (1 or 2 -> 64,
+// LeakyReLU; generator.py:204-211) and the RGB head's data gradient (3 -> 128; generator.py:273-276).  These are bound by their OUTPUT (0.84 / 1.68 GB): with K = (tap, 8
+// channels) an MFMA operand fragment is exactly one 16-byte source pixel, so the band's 18 source rows (1 KB each, one LDS-DMA apiece, a zero pixel left and right) are
+// staged ONCE and every fragment read is that image at a per-tap offset; a wave then owns 32 consecutive destination pixels: 6 MFMAs per 32 output channels, the
+// activation, a wave-private LDS transpose, and the pixels leave as 16-byte granules in memory order (32 pixels x OC channels: one contiguous run when the tensor
+// owns its pixels).  No K loop, no workgroup barrier after the staging.  Roofline: HBM (destination once).
+// --------------------------------------------------------------------------- //
+struct ClWiden3Args {
+    const __bf16* x; __bf16* y; const __bf16* wp;      // wp: the thin packed format [3 steps][OCp][32], k = (tap & 3) * 8 + channel
+    int32_t N, H, OCp, act;
+    int32_t bands, pad0;
+    float slope; int32_t pad1;
+    int64_t x_sn, y_sn;
+    int32_t x_sh, x_sw, y_sh, y_sw;
+    uint32_t x_bytes, y_bytes;
+};
+template <int OCB>      // 32-channel blocks of the destination (OC = 32 OCB)
+__global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) {
+    constexpr int W = 64, RP = (W + 2) * 16, ROWS = 18, EP = OCB * 64 + 16, GPR = OCB * 4;
+    __shared__ __attribute__((aligned(16))) char smem[ROWS * RP + 4 * 32 * EP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const int img = (int)((slot / (unsigned)a.bands) * 8u + xcd), band = (int)(slot % (unsigned)a.bands);
+    if (img >= a.N) return;
+    const int b0 = band * 16;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    if (tid < 2 * ROWS) *reinterpret_cast<u32x4*>(smem + (tid >> 1) * RP + (tid & 1) * (W + 1) * 16) = u32x4{0u, 0u, 0u, 0u};      // the zero pixels left and right of each row
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int r = wave; r < ROWS; r += 4) {      // source rows b0 - 1 .. b0 + 16; rows outside the image arrive as zeros (out-of-range offset)
+        const int sr = b0 - 1 + r;
+        const bool ok = sr >= 0 && sr < a.H;
+        const uint32_t so = ok ? (uint32_t)(((int64_t)img * a.x_sn + (int64_t)sr * a.x_sh) * 2) : 0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(smem + r * RP + 16), 16, ok ? (uint32_t)(lane * a.x_sw * 2) : 0xffffffffu, so, 0, 0);
+    }
+#endif
+    // weights: A fragments of the three K steps (12 tap slots, 9 used; the packed buffer holds zeros in the others) for every 32-channel block
+    bf16x8 wfrag[OCB][3][2];
+#pragma unroll
+    for (int ob = 0; ob < OCB; ++ob)
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) wfrag[ob][st][h] = *reinterpret_cast<const bf16x8*>(a.wp + (((int64_t)st * a.OCp + ob * 32 + l31) * 32 + (2 * h + lhi) * 8));
+    // B fragment of (step, half): the source pixel of tap = 4 step + 2 half + lhi at this lane's destination pixel; tap slots past the ninth read the zero pixel
+    uint32_t boff[3][2];
+#pragma unroll
+    for (int st = 0; st < 3; ++st)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tap = st * 4 + 2 * h + lhi;
+            boff[st][h] = tap < 9 ? (uint32_t)(((tap / 3) * (W + 2) + l31 + tap % 3) * 16) : 0xffffffffu;
+        }
+    cl_wait_vm<0>();
+    __syncthreads();
+    char* tw = smem + ROWS * RP + wave * (32 * EP);
+    const int act = a.act;
+    const float slope = a.slope;
+    for (int u = wave; u < 32; u += 4) {
+        const int r = u >> 1, half = u & 1;
+        const uint32_t ubase = (uint32_t)((r * (W + 2) + half * 32) * 16);
+        bf16x8 b8[3][2];
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) b8[st][h] = *reinterpret_cast<const bf16x8*>(smem + (boff[st][h] == 0xffffffffu ? 0u : ubase + boff[st][h]));
+#pragma unroll
+        for (int ob = 0; ob < OCB; ++ob) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 3; ++st)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ob][st][h], b8[st][h], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cl_act(acc[4 * q + e], act, slope);
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                const f32x2_ p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
+                u32x2 o;
+                o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
+                o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                *reinterpret_cast<u32x2*>(tw + l31 * EP + (ob * 32 + 8 * q + 4 * lhi) * 2) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes, before its lanes read one another's (LDS operations of a wave complete in order)
+        const uint32_t ybase = (uint32_t)(2 * ((int64_t)img * a.y_sn + (int64_t)(b0 + r) * a.y_sh + (int64_t)(half * 32) * a.y_sw));
+#pragma unroll
+        for (int it = 0; it < GPR / 2; ++it) {
+            const int idx = it * 64 + lane, px = idx / GPR, c = idx % GPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tw + px * EP + c * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(v, yrs, ybase + (uint32_t)(px * a.y_sw * 2 + c * 16), 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next unit overwrites the transpose image
+    }
+}
+
 struct ClTile { int bn, bm; };
 static ClTile cl_pick_tile(int OC) {
     if (OC > 64) return {128, 128};
@@ -1296,6 +1400,29 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     // zeros past OC — so nobody has to clear a fresh tensor's padding channels first
     const int ocs = (dst.w > 1 ? dst.sw : pad8(pl.OC)) >= pad8(pl.OC) && pl.OC % 8 ? pad8(pl.OC) : (pl.OC + 3) / 4 * 4;
     if (dst.w > 1 && dst.sw < ocs) return fail(DCV_EINVAL, "cl conv: destination pixel pitch %lld < %d stored channels", (long long)dst.sw, ocs);
+    if (thin && !accumulate && !stat) {
+        // fused form (cl_widen3x3_kernel): 2-D 3x3 / stride 1 / pad 1 direct form out of a thin source on 64-wide rows, 64 or 128 destination channels
+        static const bool no_fused = getenv("DCV_CL_NO_WIDEN3") != nullptr;      // A/B only
+        const bool direct3 = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
+        if (!no_fused && direct3 && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
+            src.d == 1 && dst.d == 1 && src.w == 64 && src.h % 16 == 0 && dst.w == 64 && dst.h == src.h && (pl.OC == 64 || pl.OC == 128) && pl.OC == ocs &&
+            (reinterpret_cast<uintptr_t>(src_p) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && src.sw >= 8 && dst.sw >= pl.OC &&
+            cl_extent_bytes(src, 8) < (1ll << 31) && cl_extent_bytes(dst, pl.OC) < (1ll << 31)) {
+            ClWiden3Args t;
+            memset(&t, 0, sizeof(t));
+            t.x = static_cast<const __bf16*>(src_p); t.y = static_cast<__bf16*>(dst_p); t.wp = static_cast<const __bf16*>(packed);
+            t.N = src.n; t.H = src.h; t.OCp = (pl.OC + cl_pick_tile(pl.OC).bn - 1) / cl_pick_tile(pl.OC).bn * cl_pick_tile(pl.OC).bn; t.act = act; t.bands = src.h / 16; t.slope = slope;
+            t.x_sn = src.sn; t.y_sn = dst.sn; t.x_sh = (int32_t)src.sh; t.x_sw = (int32_t)src.sw; t.y_sh = (int32_t)dst.sh; t.y_sw = (int32_t)dst.sw;
+            t.x_bytes = (uint32_t)cl_extent_bytes(src, 8); t.y_bytes = (uint32_t)cl_extent_bytes(dst, pl.OC);
+            const unsigned nwg = (unsigned)((src.n + 7) / 8 * 8 * t.bands);
+            hipStream_t st3 = static_cast<hipStream_t>(stream);
+            if (pl.OC == 128) hipLaunchKernelGGL((cl_widen3x3_kernel<4>), dim3(nwg), dim3(256), 0, st3, t);
+            else hipLaunchKernelGGL((cl_widen3x3_kernel<2>), dim3(nwg), dim3(256), 0, st3, t);
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_widen3x3_kernel<%d> (fused, thin source, bf16 channels-last)", pl.OC / 32);
+            DCV_LAUNCH_CHECK();
+            return DCV_OK;
+        }
+    }
     const ClTile tc = cl_pick_tile(pl.OC);
     const int OCp = (pl.OC + tc.bn - 1) / tc.bn * tc.bn;
     const int64_t xb = cl_extent_bytes(src, thin ? 8 : Cp), yb = cl_extent_bytes(dst, ocs);

@@ -88,8 +88,10 @@ class GradBucket:
     member's ``.grad`` IS its slice of it: the post-accumulate-grad hook — which also marks the bucket dirty — re-points ``p.grad`` at
     the slice (copying only when the gradient was produced elsewhere: a parameter used twice in one backward is summed by autograd into
     a tensor of its own; the weight-gradient kernels of single-use parameters write straight into the slice, ``ops._Conv.backward``).
-    ``reduce()`` is then one in-place all-reduce (sum) of the buffer — no flatten copy, no re-pointing afterwards.  Parameters whose
-    ``.grad`` is None this backward keep a stale slice that nobody reads (the set is the same on every rank: every rank runs the same graph).
+    ``reduce()`` is then one in-place all-reduce (sum) of the buffer — no flatten copy, no re-pointing afterwards.  The slice of a parameter
+    whose ``.grad`` is None this backward (the set is the same on every rank: every rank runs the same graph) is zeroed before the collective:
+    nobody reads it, but a stale slice would be multiplied by the world size at every reduction and reach inf / NaN inside the communicated
+    buffer (RCCL's NaN checks, anomaly tooling).
     `dirty` is set by autograd whenever a member receives a gradient and cleared by `reduce()`."""
 
     def __init__(self, group=None, bucket_bytes: int = 256 << 20):
@@ -159,7 +161,9 @@ class GradBucket:
         if self._flat is None:      # gradients arrived before the layout existed (world of one, force=True): adopt them now
             self._layout()
         for p in self.params:
-            if p.grad is not None and p.grad.data_ptr() != p._dcv_grad_slot.data_ptr():
+            if p.grad is None:
+                p._dcv_grad_slot.zero_()      # no gradient this backward: the stale slice must not be summed over the ranks again and again
+            elif p.grad.data_ptr() != p._dcv_grad_slot.data_ptr():
                 p._dcv_grad_slot.copy_(p.grad)
                 p.grad = p._dcv_grad_slot
                 self.copies += 1
@@ -167,6 +171,8 @@ class GradBucket:
         for a, b in self._chunks:
             self.dist.all_reduce(self._flat[a:b], op=self.dist.ReduceOp.SUM, group=self.group)
             self.collectives += 1
+        from . import ops
+        ops.new_backward_epoch()      # this backward's gradients are in the buffer: the weight-gradient ops may be handed the slices again (also when a plain Adam drives the bucket)
 
 
 class DataParallelAdam:

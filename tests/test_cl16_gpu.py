@@ -29,6 +29,7 @@ CASES = [
     ("conv2d_4s2p1_thin3_32", False, 2, 3, 32, 4, 2, 1, (64, 64), 2),
     ("conv2d_4s2p1_256_1", False, 2, 256, 1, 4, 2, 1, (8, 8), 3),
     ("conv2d_3s1p1_thin1_64", False, 2, 1, 64, 3, 1, 1, (64, 64), 2),
+    ("conv2d_3s1p1_thin2_64_n9", False, 2, 2, 64, 3, 1, 1, (32, 64), 9),     # fused thin-source kernel: two bands per image, images past a multiple of 8
     ("convT2d_4s2p1_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3),
     ("convT2d_4s2p1_288_256", True, 2, 266, 256, 4, 2, 1, (1, 1), 7),
     ("convT2d_4s1p0_latent", True, 2, 50, 128, 4, 1, 0, (1, 1), 9),
@@ -86,7 +87,9 @@ def test_conv_cl16(case):
     wd = w.detach().to(DEV).requires_grad_(True)
     y = ops_cl.conv(xc, wd, ops.conv_geom(wd, s_t, p_t, tr))
     kn = native.lib().dcv_debug_last_kernel().decode()
-    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn), kn
+    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn or "cl_widen3x3" in kn), kn
+    if name.startswith("conv2d_3s1p1_thin"):
+        assert "cl_widen3x3" in kn, kn          # the fused thin-source form
     if name.startswith("convT2d_3s1p1"):
         assert "cl_thin3x3" in kn, kn           # the fused thin-destination form is the one these shapes select
     cc, cstore, G2 = guarded_cl(cot.shape, cot.to(DEV))

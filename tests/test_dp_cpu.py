@@ -83,6 +83,8 @@ def _worker(rank, world, port, q):
     # iteration 3: no backward at all (update gated off) -> a step must not start a collective
     optA.step()
     ok &= bucket.reductions == 2
+    # the slice of a member without a gradient is zeroed before every collective (a stale slice would grow by the world size per reduction)
+    ok &= bool(torch.isfinite(bucket._flat).all()) and float(frozen._dcv_grad_slot.abs().max()) == 0.0
     w1 = torch.cat([p.detach().reshape(-1) for p in params])
     allw = [None] * world
     dist.all_gather_object(allw, (w0.numpy(), w1.numpy()))

@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 5 A/B (one box): fused thin-destination 3x3 kernel vs GEMM + col2im
+# round 5 A/B (one box): fused thin-source 3x3 kernel vs the tiled thin gather
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r5e; mkdir -p $O
+O=gpurun_out/r5f; mkdir -p $O
 timeout -k 10 500 python3 -m pytest tests/test_cl16_gpu.py -m gpu -x -q > $O/test_cl16.log 2>&1 || { tail -25 $O/test_cl16.log; exit 1; }
 tail -n 2 $O/test_cl16.log
 lt() { env $1 timeout -k 10 250 python3 tools/layer_table.py surreal-depth1 --precision bf16cl --filter "$3" --csv $O/layers_$2.csv > $O/layers_$2.txt 2>&1 || { tail -5 $O/layers_$2.txt; exit 1; }; cat $O/layers_$2.txt | tail -n 4; }
-lt DCV_CL_NO_THIN3=1 old "cgen." && lt X=1 fused "cgen." || exit 1
+lt DCV_CL_NO_WIDEN3=1 old "cgen." && lt X=1 fused "cgen." || exit 1
 B="--config surreal-depth1 --precision bf16cl --steps 12 --warmup 4 --no-cpu-baseline --no-as-trainer --no-minimal --no-secondary"
-for v in "DCV_CL_NO_THIN3=1" "X=1" "DCV_CL_NO_THIN3=1" "X=1"; do
+for v in "DCV_CL_NO_WIDEN3=1" "X=1" "DCV_CL_NO_WIDEN3=1" "X=1"; do
   env $v timeout -k 10 200 python3 bench.py $B 2> $O/bench.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],2), 'ms', round(d['value'],1))" || { tail -3 $O/bench.err; exit 1; }
 done
