@@ -249,21 +249,33 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, vo_, 0, 0, 0); \
             }                                                                                                                 \
         } else {                                                                                                              \
-            const int tap_ = st_ / a.cblk, cb_ = st_ - tap_ * a.cblk;                                                         \
-            const uint32_t to_ = (uint32_t)a.toff[tap_];                                                                      \
-            _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                                 \
-                /* granules past the operand's own channels (a 16- or 24-channel slice of a wider buffer) are padding, not the neighbour's data */ \
-                const uint32_t ok_ = ((uint32_t)(xmask[s] >> tap_) & 1u) & (uint32_t)(cb_ * 64 + 16 * xchunk[s] < a.x_cmax);   \
-                const uint32_t vo_ = ok_ ? xbase[s] + to_ : 0xffffffffu;                                                      \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, vo_, cb_ * 64, 0, 0); \
+            /* the per-lane offsets change with the TAP only: (re)formed at a tap's first channel block; the channel block rides on the scalar offset */ \
+            if (nx_cb == 0 || ragged) {                                                                                       \
+                const uint32_t to_ = (uint32_t)a.toff[nx_tap];                                                                \
+                _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                             \
+                    /* granules past the operand's own channels (a 16- or 24-channel slice of a wider buffer) are padding, not the neighbour's data */ \
+                    const uint32_t ok_ = ((uint32_t)(xmask[s] >> nx_tap) & 1u) & (uint32_t)(nx_cb * 64 + 16 * xchunk[s] < a.x_cmax); \
+                    xvo[s] = ok_ ? xbase[s] + to_ : 0xffffffffu;                                                              \
+                }                                                                                                             \
             }                                                                                                                 \
+            _Pragma("unroll") for (int s = 0; s < XPT; ++s)                                                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, xvo[s], nx_cb * 64, 0, 0); \
+            if (++nx_cb == a.cblk) { nx_cb = 0; ++nx_tap; }                                                                   \
         }                                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                       \
             if ((BN * 4) % 256 == 0 || wave * 64 + 256 * j < BN * 4)                                                          \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(wb_ + (j * 256 + wave * 64) * 16), 16, wvo[j], st_ * wstep, 0, 0); \
     }
 #else
-#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; }
+#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; (void)xvo; (void)nx_tap; (void)nx_cb; (void)ragged; }
+#endif
+    // issue state of the thick form: K steps are issued in order, so (tap, channel block) of the next one are counters, not a division per step
+    [[maybe_unused]] uint32_t xvo[XPT];
+    [[maybe_unused]] int nx_tap = 0, nx_cb = 0;
+#ifdef DCV_CL_NO_VO_CACHE
+    [[maybe_unused]] const bool ragged = true;      // A/B build: offsets re-formed at every K step
+#else
+    [[maybe_unused]] const bool ragged = a.x_cmax < a.cblk * 64;      // the last channel block is partly padding: granule validity then depends on the block
 #endif
 
     f32x16 acc[TOC][TM];

@@ -15,7 +15,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcvgan_hip.so")
+LIB_PATH = os.environ.get("DCV_LIB_PATH") or os.path.join(_HERE, "libdcvgan_hip.so")      # DCV_LIB_PATH: another build of the same library (A/B runs of tools/)
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
 DCV_EUNSUPPORTED = -4
