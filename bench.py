@@ -15,13 +15,14 @@ every rank runs the step on its own batch and RNG stream; the gradients of a pha
 bucket inside the optimiser wrapper (dcvgan_amd/optim.py).
 
 Rank 0 prints ONE JSON line.
-  roofline      bound "mfma".  achieved / frac: the dominant kernel (cgen.up_blocks.5 forward, the step's largest single
-                GEMM: 2 * M * OC * K FLOP per launch) timed alone with HIP events on the stream it is launched on,
-                against the dense fp32 MFMA peak; `step` holds the whole iteration priced the same way
-                (conv / convT / GRU FLOPs of the as-written schedule x videos/s), `hbm` the iteration's algorithmic
-                bytes per second against 8 TB/s.  `traffic` (HBM bytes per launch of the dominant kernel from
-                rocprofv3 PMC passes) cannot be collected from inside the process: it is read from the committed
-                profile of the SAME batch size, else null.
+  roofline      bound "mfma".  achieved / frac: the WHOLE ITERATION — conv / convT / GRU FLOPs of the as-written schedule
+                 x videos/s against the dense MFMA peak of the precision in use; `mfma_floor_ms` /
+                `hbm_floor_ms` are the iteration's floors under that peak and under 8 TB/s (algorithmic bytes of the
+                precision's storage type).  `dominant_kernel`: cgen.up_blocks.5 forward, the step's largest single GEMM
+                (2 * M * OC * K FLOP per launch), timed alone with HIP events on the stream it is launched on.  `traffic`
+                (HBM bytes per iteration / per launch of the dominant kernel from rocprofv3 PMC passes) cannot be
+                collected from inside the process: it is read from the committed profile of the SAME kernel sources
+                (sha256), config and batch size, else null.
   cpu_baseline  the CPU oracle's step (pure-torch restatement of the reference trainer, pinned to the reference by
                 tests/golden) on this host's cores — rank 0, N = 1 only.
 """
@@ -216,19 +217,20 @@ def committed_traffic(batch, kernel):
     return None, None
 
 
-def committed_step_traffic(config, batch):
+def committed_step_traffic(config, batch, cl=False):
     """HBM bytes per ITERATION from the newest committed whole-step PMC passes (tools/pmc_step.sh), under the same rule: same source digest,
     same config and batch, else null.  FETCH_SIZE doubled as the guide prescribes for 16-byte-per-lane streams (every large read of the step
     is one: LDS-DMA granules, 16-byte elementwise groups); the raw sum is given beside it."""
     import glob
     from dcvgan_amd import native
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_summary.json")), reverse=True):
+    pattern = "r*_pmc_step_bf16cl_summary.json" if cl else "r*_pmc_step_summary.json"      # cl: the bf16 channels-last path's passes (digest over its sources too)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             t = json.load(open(f))
         except Exception:
             continue
         meta = t.get("__meta__") or {}
-        if meta.get("csrc_sha256") != native.csrc_digest() or meta.get("config") != config or int(meta.get("batch", -1)) != int(batch):
+        if meta.get("csrc_sha256") != native.csrc_digest(cl=cl) or meta.get("config") != config or int(meta.get("batch", -1)) != int(batch):
             return None, {"note": f"profiles/{os.path.basename(f)}: taken from other sources / config / batch ({meta or 'no metadata'}): not reported"}
         steps = max(1, int(meta.get("steps", 1)))
         fe = sum(v.get("FETCH_SIZE", 0.0) for k, v in t.items() if k != "__meta__") * 1024 / steps
@@ -298,9 +300,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and not a.cpus and not a.all_ranks_on_device0:
-        # every rank (spawned by us or by torch.distributed.run) enqueues ~900 launches per iteration from one Python thread: keep that thread and
-        # its allocations on the NUMA node its GPU hangs off
+    if not a.cpus and not a.all_ranks_on_device0:
+        # every rank (spawned by us or by torch.distributed.run; also the single rank of an N = 1 run) enqueues ~900 launches per iteration from one Python
+        # thread: keep that thread and its allocations on the NUMA node its GPU hangs off
         numa_cpus = gpu_numa_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         if numa_cpus:
             os.sched_setaffinity(0, set(numa_cpus))
@@ -369,6 +371,7 @@ def main():
         runner.step(xc, xg, i % cfg.video_length)
     dt, out = timed(runner, a.steps, a.warmup)
     launches = native.launch_count() - n0
+    peak_mem_headline = torch.cuda.max_memory_allocated(dev)      # the headline iteration's own peak: read before any secondary leg allocates
     losses = {k: float(v) for k, v in out.items()}
     assert all(x == x and abs(x) < 1e4 for x in losses.values()), losses
 
@@ -435,6 +438,7 @@ def main():
         for prec, cname in legs:
             c2 = CONFIGS[cname]
             torch.cuda.empty_cache()       # the headline's cached blocks (fp32 tensors of another config) go back to the driver before a leg allocates its own
+            torch.cuda.reset_peak_memory_stats(dev)
             try:
                 if prec == "bf16cl":
                     ops_cl.enable(True)
@@ -469,7 +473,13 @@ def main():
                 pk2 = PEAK_BF16_MFMA_TFLOPS if prec == "bf16cl" else PEAK_BF16_MFMA_TFLOPS / 6.0
                 f2 = flops_per_video_iteration(c2)
                 secondary[f"{prec}:{cname}"] = {"value": c2.batchsize * world / (d2 / ns), "unit": "videos/s", "ms_per_step": d2 / ns * 1e3, "steps": ns, "per_gpu_batch": c2.batchsize,
-                                                "frac_of_its_mfma_peak": f2 * (c2.batchsize / (d2 / ns)) / 1e12 / pk2, "peak_tflops": pk2, "losses_last_step": l2}
+                                                "frac_of_its_mfma_peak": f2 * (c2.batchsize / (d2 / ns)) / 1e12 / pk2, "peak_tflops": pk2,
+                                                "mfma_floor_ms": f2 * c2.batchsize / (pk2 * 1e12) * 1e3,
+                                                "hbm_floor_ms": ALGORITHMIC_HBM_GB_PER_VIDEO_ITERATION * (0.5 if prec == "bf16cl" else 1.0) * c2.batchsize / PEAK_HBM_GBPS * 1e3,
+                                                "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9, "losses_last_step": l2}
+                if prec == "bf16cl":
+                    tr2, trd2 = committed_step_traffic(cname, c2.batchsize, cl=True)
+                    secondary[f"{prec}:{cname}"].update({"traffic": tr2, "traffic_detail": trd2})
                 del m2, o2, r2, xc2, xg2
             except Exception as e:      # a secondary leg may fail; the headline line is still printed
                 secondary[f"{prec}:{cname}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -509,6 +519,8 @@ def main():
                                        "the dominant kernel timed alone (rounds 2-3's roofline.frac) is roofline.dominant_kernel; traffic = HBM bytes per ITERATION "
                                        "from the committed PMC passes of this very source (else null), dominant_kernel.traffic = per launch of that kernel",
                          "flops_per_video_step": f_step,
+                         "mfma_floor_ms": f_step * B / (peak * 1e12) * 1e3,
+                         "hbm_floor_ms": gb_step * (0.5 if a.precision == "bf16cl" else 1.0) / PEAK_HBM_GBPS * 1e3,
                          "dominant_kernel": dict(probe, achieved=probe["tflops"], frac=probe["tflops"] / peak, traffic=traffic, traffic_detail=traffic_detail),
                          "step": {"achieved": step_tflops, "frac": step_tflops / peak, "flops_per_video_step": f_step},
                          "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,
@@ -518,7 +530,7 @@ def main():
             "as_trainer": as_trainer,
             "secondary_precisions": secondary,
             "losses_last_step": losses,
-            "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+            "peak_mem_gb": peak_mem_headline / 1e9,
         }
         print(json.dumps(line))
     if world > 1:

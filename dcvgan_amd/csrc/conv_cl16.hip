@@ -154,17 +154,26 @@ __device__ __forceinline__ uint32_t cl_dim_mask(const ClDim& t, int o) {
 // positions, K step 32.  LDS: two stages of [BM rows][64 B] activations + [BN rows][64 B] weights; the four 16-byte chunks of a
 // row are XOR-swizzled with (row >> 2) & 3 on the DMA's SOURCE side (an LDS-DMA lands lane-linear), which makes the fragment
 // reads "32 rows x one chunk" (ds_read_b128) conflict-free.
+#ifdef DCV_CL_STAMP
+// cycle-stamped build (tools/build_stamp_cl.sh, tools/stamps_cl.py): per wave of the first 4096 workgroups {prologue, wait + barrier, DMA issue, fragment reads + MFMA issue,
+// epilogue, lifetime, steps} in shader-clock cycles
+__device__ unsigned long long g_cl_stamps[4096][8][8];
+#define CL_T() __builtin_readcyclecounter()
+#else
+#define CL_T() 0ull
+#endif
 template <int N>
 __device__ __forceinline__ void cl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NS = LDS stages: the DMAs of K step st + NS - 1 are issued at the top of step st (NS = 2: one step ahead, four workgroups per CU; NS = 3: two steps
 // ahead behind a counted vmcnt wait, three workgroups per CU)
 template <int TOC, int TM, int WOC, int WM, bool THIN, int NS>
-__global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pack) {
-    constexpr int BN = 32 * TOC * WOC, BM = 32 * TM * WM;
-    constexpr int XPT = BM * 4 / 256, WPT = (BN * 4 + 255) / 256;
+__global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gather_kernel(const ClGatherPack pack) {
+    constexpr int BN = 32 * TOC * WOC, BM = 32 * TM * WM, NT = 64 * WOC * WM;      // NT threads: 4 waves, or 8 (128 x 256 tile: 3 LDS-DMA granules per wave and 8 MFMAs instead of 4)
+    constexpr int XPT = BM * 4 / NT, WPT = (BN * 4 + NT - 1) / NT;
+    static_assert((BM * 4) % NT == 0 && (BM * (BN / 8)) % NT == 0 && BM <= NT, "tile / thread-count combination");
     constexpr int XB = BM * 64, WB = BN * 64, STAGE = XB + WB;
-    static_assert(WOC * WM == 4, "4 waves");
+    static_assert(WOC * WM == 4 || WOC * WM == 8, "4 or 8 waves");
     static_assert(NS >= 2 && NS <= 4, "2-4 stages");
     // epilogue image: the tile as [position][BN channels] bf16, pitch BN * 2 + 16 bytes, + one byte offset per position row
     constexpr int EPITCH = BN * 2 + 16, EPI = BM * EPITCH + BM * 4;
@@ -179,6 +188,8 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
     const ClGatherArgs& a = pack.c[gi / (unsigned)pack.tiles_oc];
     const int m0 = m_t * BM, oc0 = oc_t * BN;
     if (m0 >= a.M) return;
+    [[maybe_unused]] const unsigned long long ts_start = CL_T();
+    [[maybe_unused]] unsigned long long ts_wait = 0, ts_issue = 0, ts_mma = 0;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
     int xchunk[XPT];
 #pragma unroll
     for (int s = 0; s < XPT; ++s) {
-        const int g = tid + 256 * s, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
+        const int g = tid + NT * s, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
         const int m = m0 + row;
         xchunk[s] = c;
         uint64_t vm = 0;
@@ -218,10 +229,17 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
             const int64_t e = (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base) * a.x_sd + (int64_t)((int)oh * a.th.mul + a.th.base) * a.x_sh +
                               (int64_t)((int)ow * a.tw.mul + a.tw.base) * a.x_sw;
             base = (uint32_t)(2 * e) + (THIN ? 0u : (uint32_t)(16 * c));
-            for (int t = 0; t < a.T; ++t) {
-                const uint32_t sel = (uint32_t)a.tsel[t];
-                const uint32_t ok = (md >> (sel & 3)) & (mh >> ((sel >> 2) & 3)) & (mw >> ((sel >> 4) & 3)) & 1u;
-                vm |= (uint64_t)ok << t;
+            // bit t = tap t in range, t = (ud, uh, uw) row-major as the host enumerates them (tsel).  Nested loops over the per-dim counts: no table load per
+            // tap (the tsel[t] scalar loads of the first form were a chain of ~250-cycle latencies: 16 k cycles of prologue at 64 taps; cycle stamps, round 5)
+            {
+                int t = 0;
+                for (int ud = 0; ud < a.td.n; ++ud) {
+                    const uint32_t bd = (md >> ud) & 1u;
+                    for (int uh = 0; uh < a.th.n; ++uh) {
+                        const uint32_t bh = bd & (mh >> uh);
+                        for (int uw = 0; uw < a.tw.n; ++uw, ++t) vm |= (uint64_t)(bh & (mw >> uw) & 1u) << t;
+                    }
+                }
             }
         }
         xbase[s] = base;
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
     uint32_t wvo[WPT];
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        const int g = tid + 256 * j, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
+        const int g = tid + NT * j, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
         wvo[j] = (uint32_t)(((oc0 + row) * 32 + c * 8) * 2);
     }
     const uint32_t wstep = (uint32_t)a.OCp * 64u;
@@ -246,12 +264,12 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
                 const int t_ = st_ * 4 + xchunk[s];                                                                           \
                 const uint32_t ok_ = (uint32_t)(xmask[s] >> t_) & 1u;                                                         \
                 const uint32_t vo_ = ok_ ? xbase[s] + (uint32_t)toff_l[t_ & 63] : 0xffffffffu;                               \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, vo_, 0, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * NT + wave * 64) * 16), 16, vo_, 0, 0, 0); \
             }                                                                                                                 \
         } else {                                                                                                              \
             /* the per-lane offsets change with the TAP only: (re)formed at a tap's first channel block; the channel block rides on the scalar offset */ \
             if (nx_cb == 0 || ragged) {                                                                                       \
-                const uint32_t to_ = (uint32_t)a.toff[nx_tap];                                                                \
+                const uint32_t to_ = to_cur;                                                                                  \
                 _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                             \
                     /* granules past the operand's own channels (a 16- or 24-channel slice of a wider buffer) are padding, not the neighbour's data */ \
                     const uint32_t ok_ = ((uint32_t)(xmask[s] >> nx_tap) & 1u) & (uint32_t)(nx_cb * 64 + 16 * xchunk[s] < a.x_cmax); \
@@ -259,19 +277,22 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
                 }                                                                                                             \
             }                                                                                                                 \
             _Pragma("unroll") for (int s = 0; s < XPT; ++s)                                                                   \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * 256 + wave * 64) * 16), 16, xvo[s], nx_cb * 64, 0, 0); \
-            if (++nx_cb == a.cblk) { nx_cb = 0; ++nx_tap; }                                                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(xb_ + (s * NT + wave * 64) * 16), 16, xvo[s], nx_cb * 64, 0, 0); \
+            if (++nx_cb == a.cblk) { nx_cb = 0; ++nx_tap; to_cur = (uint32_t)__builtin_amdgcn_readlane(toff_v, nx_tap & 63); }   /* lane t holds tap t's offset: no memory access in the loop */ \
         }                                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < WPT; ++j)                                                                       \
-            if ((BN * 4) % 256 == 0 || wave * 64 + 256 * j < BN * 4)                                                          \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(wb_ + (j * 256 + wave * 64) * 16), 16, wvo[j], st_ * wstep, 0, 0); \
+            if ((BN * 4) % NT == 0 || wave * 64 + NT * j < BN * 4)                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(wb_ + (j * NT + wave * 64) * 16), 16, wvo[j], st_ * wstep, 0, 0); \
     }
 #else
-#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; (void)xvo; (void)nx_tap; (void)nx_cb; (void)ragged; }
+#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; (void)xvo; (void)nx_tap; (void)nx_cb; (void)ragged; (void)to_cur; (void)toff_v; }
 #endif
     // issue state of the thick form: K steps are issued in order, so (tap, channel block) of the next one are counters, not a division per step
     [[maybe_unused]] uint32_t xvo[XPT];
     [[maybe_unused]] int nx_tap = 0, nx_cb = 0;
+    // tap offsets: lane t keeps toff[t]; the loop picks the next tap's with v_readlane (a scalar load of toff[tap] at every tap boundary stalled the wave ~250 cycles)
+    [[maybe_unused]] const int toff_v = a.toff[lane];
+    [[maybe_unused]] uint32_t to_cur = (uint32_t)a.toff[0];
 #ifdef DCV_CL_NO_VO_CACHE
     [[maybe_unused]] const bool ragged = true;      // A/B build: offsets re-formed at every K step
 #else
@@ -305,13 +326,15 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
 
     const int nst = a.nsteps;
     // vector-memory instructions one K step costs THIS wave (the weight tile of a 32-channel tile is 128 granules: waves 0-1 only)
-    const bool wfull = (BN * 4) % 256 == 0 || wave * 64 + 256 * (WPT - 1) < BN * 4;
+    const bool wfull = (BN * 4) % NT == 0 || wave * 64 + NT * (WPT - 1) < BN * 4;
     CL_ISSUE(0, 0)
     if constexpr (NS >= 3) { if (nst > 1) CL_ISSUE(1, 1) }
     if constexpr (NS >= 4) { if (nst > 2) CL_ISSUE(2, 2) }
+    [[maybe_unused]] const unsigned long long ts_loop = CL_T();
     int buf = 0;
     [[maybe_unused]] int nbuf = NS - 1;      // stage of step st; stage the step issued now lands in
     for (int st = 0; st < nst; ++st) {
+        [[maybe_unused]] const unsigned long long t0_ = CL_T();
         // step st's granules have landed: all but the (NS - 2) younger steps' instructions of this wave are done
         if constexpr (NS == 2) cl_wait_vm<0>();
         else {
@@ -321,7 +344,9 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
             else { if (wfull) cl_wait_vm<2 * (XPT + WPT)>(); else cl_wait_vm<2 * (XPT + WPT - 1)>(); }
         }
         __syncthreads();
+        [[maybe_unused]] const unsigned long long t1_ = CL_T();
         if (st + NS - 1 < nst) CL_ISSUE(st + NS - 1, nbuf)
+        [[maybe_unused]] const unsigned long long t2_ = CL_T();
         const char* sb = smem + buf * STAGE;
         nbuf = buf;
         buf = buf + 1 == NS ? 0 : buf + 1;
@@ -342,7 +367,11 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i][s], b8[j][s], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+#ifdef DCV_CL_STAMP
+        { const unsigned long long t3_ = CL_T(); ts_wait += t1_ - t0_; ts_issue += t2_ - t1_; ts_mma += t3_ - t2_; }
+#endif
     }
+    [[maybe_unused]] const unsigned long long ts_epi = CL_T();
 
     // ---- epilogue
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
@@ -392,8 +421,8 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
         __syncthreads();
         constexpr int GPR = BN / 8;                          // 16-byte granules per position row
 #pragma unroll
-        for (int s = 0; s < BM * GPR / 256; ++s) {
-            const int idx = tid + 256 * s, row = idx / GPR, c = idx % GPR;
+        for (int s = 0; s < BM * GPR / NT; ++s) {
+            const int idx = tid + NT * s, row = idx / GPR, c = idx % GPR;
             const uint32_t vo = rowoff[row];
             const int oc = oc0 + 8 * c;
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * EPITCH + c * 16);
@@ -463,13 +492,20 @@ __global__ __launch_bounds__(256, 2) void cl_gather_kernel(const ClGatherPack pa
             }
         __syncthreads();
         float* __restrict__ dst = a.stat + ((int64_t)(a.stat_row0 + m_t) * a.OCp + oc0) * 2;
-        for (int e = threadIdx.x; e < 2 * BN; e += 256) {
+        for (int e = threadIdx.x; e < 2 * BN; e += NT) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += sred[w * BN * 2 + e];
             dst[e] = t;
         }
     }
+#ifdef DCV_CL_STAMP
+    if (blockIdx.x < 4096 && lane == 0) {
+        const unsigned long long te = CL_T();
+        unsigned long long* o = g_cl_stamps[blockIdx.x][wave];
+        o[0] = ts_loop - ts_start; o[1] = ts_wait; o[2] = ts_issue; o[3] = ts_mma; o[4] = te - ts_epi; o[5] = te - ts_start; o[6] = (unsigned long long)nst; o[7] = ts_start;
+    }
+#endif
 }
 #undef CL_ISSUE
 
@@ -1103,8 +1139,18 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
 }
 
 struct ClTile { int bn, bm; };
+// (oc, positions) tile of a destination with OC channels.  Two more tiles exist and are OFF by default (DCV_CL_TILES: bit 0 = 128 x 256, bit 1 = 96-wide), both
+// measured neutral in round 5 (profiles/r05_ab_cl16.txt, call 7: layer table 32.6 / 32.7 / 32.6 / 32.8 ms, iteration 41.7-42.2 ms for all four settings):
+// 128 x 256 on 8 waves (512 threads) issues 3 LDS-DMA instructions per wave and 8 MFMAs instead of 4 — worth 0-7 % per layer, the 8-wave barrier takes it back;
+// 96 x 256 (channel counts that are multiples of 96 but not of 128: the geometry generator at ngf 96) saves the padded quarter of a 128-wide tile but runs at 168
+// registers = two workgroups per CU.
+static int cl_tile_opts() {
+    static const int v = getenv("DCV_CL_TILES") ? atoi(getenv("DCV_CL_TILES")) : 0;
+    return v;
+}
 static ClTile cl_pick_tile(int OC) {
-    if (OC > 64) return {128, 128};
+    if ((cl_tile_opts() & 2) && OC > 64 && OC % 96 == 0 && OC % 128 != 0) return {96, 256};
+    if (OC > 64) return (cl_tile_opts() & 1) ? ClTile{128, 256} : ClTile{128, 128};
     if (OC > 32) return {64, 256};
     return {32, 256};
 }
@@ -1169,13 +1215,21 @@ static int64_t cl_extent_bytes(const dcv_dims5& d, int cpad) {
     return 2 * ((int64_t)(d.n - 1) * d.sn + (int64_t)(d.d - 1) * d.sd + (int64_t)(d.h - 1) * d.sh + (int64_t)(d.w - 1) * d.sw + cpad);
 }
 
+static void cl_launch_tile(const ClTile tc, const ClGatherPack& pk, bool thin, dim3 grid, hipStream_t s);
 // (Round 5, measured and not instantiated: NS = 3 and 4 — two / three K steps in flight behind counted vmcnt waits, at 3 or 2 workgroups per CU instead of 4 —
 // ran the surreal-depth1 layer table in 39.5 / 41.3 ms against 37.9 and the iteration in 49.3 / 51.4 ms against 47.2 (profiles/r05_ab_cl16.txt): what bounds the
 // loop is the issue cost of the LDS-DMA instructions, 4-5 per wave and K step against 8 MFMAs, not the distance of the prefetch; fewer waves per SIMD lose more.)
 template <int TOC, int TM, int WOC, int WM>
 static void cl_launch_gather(const ClGatherPack& pk, bool thin, dim3 grid, hipStream_t s) {
-    if (thin) hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, true, 2>), grid, dim3(256), 0, s, pk);
-    else hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, false, 2>), grid, dim3(256), 0, s, pk);
+    if (thin) hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, true, 2>), grid, dim3(64 * WOC * WM), 0, s, pk);
+    else hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, false, 2>), grid, dim3(64 * WOC * WM), 0, s, pk);
+}
+static void cl_launch_tile(const ClTile tc, const ClGatherPack& pk, bool thin, dim3 grid, hipStream_t s) {
+    if (tc.bn == 128 && tc.bm == 256) cl_launch_gather<2, 2, 2, 4>(pk, thin, grid, s);
+    else if (tc.bn == 128) cl_launch_gather<2, 2, 2, 2>(pk, thin, grid, s);
+    else if (tc.bn == 96) cl_launch_gather<3, 2, 1, 4>(pk, thin, grid, s);
+    else if (tc.bn == 64) cl_launch_gather<2, 2, 1, 4>(pk, thin, grid, s);
+    else cl_launch_gather<1, 2, 1, 4>(pk, thin, grid, s);
 }
 
 
@@ -1232,6 +1286,14 @@ static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_d
 using namespace dcv;
 
 extern "C" {
+
+#ifdef DCV_CL_STAMP
+int dcv_cl_debug_read_stamps(unsigned long long* host, int zero) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cl_stamps), sizeof(g_cl_stamps)) != hipSuccess) return -1;
+    if (zero) { static unsigned long long z[8]; (void)z; hipMemset(nullptr, 0, 0); void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_cl_stamps)) == hipSuccess) (void)hipMemset(p, 0, sizeof(g_cl_stamps)); }
+    return 0;
+}
+#endif
 
 size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
     ClPlan pl;
@@ -1364,9 +1426,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     for (int i = 1; i < 4; ++i) pk.c[i] = pk.c[0];
     pk.ncls = 1; pk.tiles_oc = OCgp / tc.bn; pk.tiles_m = (int)((Msrc + tc.bm - 1) / tc.bm);
     const dim3 grid((unsigned)((pk.tiles_m + 7) / 8 * 8 * pk.tiles_oc));
-    if (tc.bn == 128) cl_launch_gather<2, 2, 2, 2>(pk, false, grid, st);
-    else if (tc.bn == 64) cl_launch_gather<2, 2, 1, 4>(pk, false, grid, st);
-    else cl_launch_gather<1, 2, 1, 4>(pk, false, grid, st);
+    cl_launch_tile(tc, pk, false, grid, st);
     DCV_LAUNCH_CHECK();
     // (2) gather the taps of every destination pixel
     ClCol2imArgs c;
@@ -1503,9 +1563,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     for (int i = n; i < 4; ++i) pk.c[i] = pk.c[0];
     pk.ncls = n; pk.tiles_oc = OCp / tc.bn; pk.tiles_m = (int)maxtm;
     const dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
-    if (tc.bn == 128) cl_launch_gather<2, 2, 2, 2>(pk, thin, grid, st);
-    else if (tc.bn == 64) cl_launch_gather<2, 2, 1, 4>(pk, thin, grid, st);
-    else cl_launch_gather<1, 2, 1, 4>(pk, thin, grid, st);
+    cl_launch_tile(tc, pk, thin, grid, st);
     snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile%s> (%d class%s, bf16 channels-last)", tc.bn, tc.bm, thin ? ", thin" : "", n, n == 1 ? "" : "es");
     DCV_LAUNCH_CHECK();
     return DCV_OK;

@@ -37,7 +37,7 @@ sq = per_dispatch("SQ", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_
 F = B * 16
 algo = (F * 128 * 32 * 32 + F * 64 * 64 * 64 + 128 * 64 * 16) * 4
 print(json.dumps({
-    "kernel": KERNEL[0], "git_head": os.environ.get("GIT_HEAD"), "csrc_sha256": native.csrc_digest(), "layer": "cgen.up_blocks.5 forward", "batch": B,
+    "kernel": KERNEL[0], "git_head": os.environ.get("GIT_HEAD") or (open(".git_head").read().strip() if os.path.exists(".git_head") else None), "csrc_sha256": native.csrc_digest(), "layer": "cgen.up_blocks.5 forward", "batch": B,
     "fetch_size_bytes_raw": fe, "fetch_size_bytes_corrected_x2": 2 * fe, "write_size_bytes": wr,
     "hbm_bytes_per_launch": 2 * fe + wr, "algorithmic_bytes_per_launch": algo, "traffic_over_algorithmic": (2 * fe + wr) / algo,
     # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD... normalised as in tools/pmc_step.sh: busy / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)

@@ -4,6 +4,7 @@
 # the whole step's per-kernel PMC table; the per-layer tables of the three GPU configs.  Outputs in gpurun_out/round/
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
+export GIT_HEAD=${GIT_HEAD:-$(cat .git_head 2>/dev/null || echo unknown)}
 O=gpurun_out/round; rm -rf $O; mkdir -p $O; rm -rf /tmp/rp /tmp/pd_*
 timeout -k 10 600 python3 bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err || { tail -3 $O/bench.err; exit 1; }
 echo "bench done"; cut -c1-200 $O/bench.json
