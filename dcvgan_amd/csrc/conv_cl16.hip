@@ -756,6 +756,7 @@ struct ClWgradReduceArgs {
     float* dw;
     int32_t S, tiles, tiles_d, gblocks, gcb, ntpt, T, DC, GC, lpe;
     int64_t ws_d;
+    int32_t accumulate, pad;     // dw += sum (dcv_cl_conv_backward_weight_acc)
 };
 __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduceArgs a) {
     // LPE lanes per output element (1, or 64 when there are many position splits: a thread walking 1000+ slabs 64 KB apart is a serial chain of
@@ -779,7 +780,8 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduc
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (l != 0) return;
     }
-    a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
+    float* o = a.dw + (int64_t)dc * a.ws_d + (int64_t)gc * a.T + t;
+    *o = a.accumulate ? *o + s : s;
 }
 
 // The same reduction walked in SLAB order: a workgroup owns EL consecutive slab elements and GR groups of slabs (EL x GR = 256 threads); a thread sums slabs g, g + GR, ... of its
@@ -814,7 +816,8 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_slab_kernel(const ClWgrad
     const int tl = vc / a.gcb, gcl = vc - tl * a.gcb;
     const int dc = d_t * 128 + r, gc = gbk * 128 + gcl, t = tg * a.ntpt + tl;
     if (dc >= a.DC || gc >= a.GC || tl >= a.ntpt || t >= a.T) return;
-    a.dw[(int64_t)dc * a.ws_d + (int64_t)gc * a.T + t] = s;
+    float* o = a.dw + (int64_t)dc * a.ws_d + (int64_t)gc * a.T + t;
+    *o = a.accumulate ? *o + s : s;
 }
 
 struct ClPackThinArgs {
@@ -1608,8 +1611,8 @@ size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, 
 }
 
 // dw (fp32, torch layout) = corr(x, dy); x and dy bf16 channels-last.  conv: dense = dy, gathered = x; transposed conv: dense = x, gathered = dy.
-int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
-                                void* ws, size_t ws_bytes, void* stream) {
+static int cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                   void* ws, size_t ws_bytes, void* stream) {
     if (!g || !x || !xd || !dy || !dyd || !dw || !ws) return fail(DCV_EINVAL, "cl_conv_backward_weight: null pointer");
     ClPlan chk;
     int rc = cl_make_plan(0, g, xd, dyd, &chk);      // validates the geometry
@@ -1699,7 +1702,7 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
         ClWgradReduceArgs a;
         memset(&a, 0, sizeof(a));
         a.slab = slab; a.dw = dw; a.S = p.S; a.tiles = p.tiles; a.tiles_d = p.tiles_d; a.gblocks = p.gblocks; a.gcb = p.gcb; a.ntpt = p.ntpt; a.T = p.T;
-        a.DC = D.c; a.GC = G.c; a.ws_d = (int64_t)G.c * p.T;
+        a.DC = D.c; a.GC = G.c; a.ws_d = (int64_t)G.c * p.T; a.accumulate = accumulate ? 1 : 0;
         const int64_t tot = (int64_t)D.c * G.c * p.T;
         static const bool old_reduce = getenv("DCV_CL_OLD_WGRAD_REDUCE") != nullptr;      // A/B only
         const int64_t nel = (int64_t)p.tiles * (128 * 128);
@@ -1715,6 +1718,15 @@ int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv
     }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, bf16 channels-last)", p.tiles, p.S);
     return DCV_OK;
+}
+int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
+                                void* ws, size_t ws_bytes, void* stream) {
+    return cl_conv_backward_weight(g, x, xd, dy, dyd, dw, 0, ws, ws_bytes, stream);
+}
+// dw = (accumulate ? dw : 0) + corr(x, dy): as dcv_conv_backward_weight_acc
+int dcv_cl_conv_backward_weight_acc(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    return cl_conv_backward_weight(g, x, xd, dy, dyd, dw, accumulate, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -48,6 +48,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 std::atomic<int> g_precision{0};
 // per-call override from dcv_conv_geom.mfma (1 = fp32, 2 = bf16; 0 = the process default above), valid while a dcv_conv_* entry point runs on this thread
 static thread_local int t_precision = -1;
+// dcv_conv_backward_weight_acc: the slab reduce of the calling thread's weight-gradient call ADDS its sum to dw (set around the call, read at the three reduce launches)
+static thread_local int t_wgrad_acc = 0;
 static inline int eff_precision() { return t_precision >= 0 ? t_precision : g_precision.load(std::memory_order_relaxed); }
 struct PrecisionScope {
     int saved;
@@ -2291,7 +2293,7 @@ __global__ __launch_bounds__(256) void thin_wgrad3_kernel(const ThinWgradArgs a)
 // (independent loads, 4-way unrolled) and wave 0 combines the four partial sums in a fixed order:
 // bitwise reproducible, and 16x more loads in flight than one thread walking all S splits.
 // J % 4 == 0 (every 4x4-tap layer): four consecutive j per lane, 16-byte loads — the same order of additions per element
-__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp) {
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp, int acc) {
     __shared__ float4 part[3][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int J4 = J >> 2;
@@ -2313,11 +2315,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restr
     __syncthreads();
     if (grp == 0 && ok) {
         const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane];
-        *reinterpret_cast<float4*>(dw + (int64_t)dc * J + j) = float4{((v.x + a.x) + b.x) + c.x, ((v.y + a.y) + b.y) + c.y, ((v.z + a.z) + b.z) + c.z, ((v.w + a.w) + b.w) + c.w};
+        float4 r = float4{((v.x + a.x) + b.x) + c.x, ((v.y + a.y) + b.y) + c.y, ((v.z + a.z) + b.z) + c.z, ((v.w + a.w) + b.w) + c.w};
+        float4* o = reinterpret_cast<float4*>(dw + (int64_t)dc * J + j);
+        if (acc) { const float4 old = *o; r = float4{old.x + r.x, old.y + r.y, old.z + r.z, old.w + r.w}; }      // = the sum autograd would form of the two gradients (one rounding, commutative)
+        *o = r;
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp, int acc) {
     __shared__ float part[3][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -2337,7 +2342,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const float v = (s0 + s1) + (s2 + s3);
     if (grp > 0) part[grp - 1][lane] = v;
     __syncthreads();
-    if (grp == 0 && ok) dw[i] = ((v + part[0][lane]) + part[1][lane]) + part[2][lane];
+    if (grp == 0 && ok) {
+        const float r = ((v + part[0][lane]) + part[1][lane]) + part[2][lane];
+        dw[i] = acc ? dw[i] + r : r;
+    }
 }
 
 // --------------------------------------------------------------------------- //
@@ -3254,7 +3262,7 @@ static int try_thin_wgrad(const float* D, const dcv_dims5& dd, const float* G, c
     DCV_NOTE_KERNEL("thin_wgrad3_kernel<%d, %d> (%d slabs)", GC, dcw, nslab);
     DCV_LAUNCH_CHECK();
     const int64_t tot = (int64_t)DC * J;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, nslab, DC, J, DC, J);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, nslab, DC, J, DC, J, t_wgrad_acc);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -3427,9 +3435,9 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     DCV_LAUNCH_CHECK();
     const int64_t tot = (int64_t)DC * J;
     if (J % 4 == 0 && Jp % 4 == 0 && (reinterpret_cast<uintptr_t>(R) & 15) == 0)
-        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((tot / 4 + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp);
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((tot / 4 + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp, t_wgrad_acc);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, S2, DC, J, DCp, Jp, t_wgrad_acc);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -3485,7 +3493,7 @@ int dcv_set_precision(int mode) {
     return DCV_OK;
 }
 int dcv_get_precision(void) { return g_precision.load(); }
-int dcv_version(void) { return 2; }
+int dcv_version(void) { return 3; }
 void dcv_abi_struct_sizes(size_t out[3]) {
     if (!out) return;
     out[0] = sizeof(dcv_dims5); out[1] = sizeof(dcv_conv_geom); out[2] = sizeof(dcv_wpack);
@@ -3718,6 +3726,17 @@ int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_d
     if (!g->transposed)
         return run_wgrad(dy, *dyd, x, *xd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "conv_bwd_weight", nullptr);
     return run_wgrad(x, *xd, dy, *dyd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "convT_bwd_weight", nullptr);
+}
+
+// dw = (accumulate ? dw : 0) + corr(x, dy): a weight used twice in one backward (a discriminator on the real and the fake batch, trainer.py:299-309) or whose
+// .grad already holds an earlier backward's gradient (the G phase on top of the D phase, trainer.py:356 after :319) gets its sum formed by the slab reduce
+// instead of by a separate elementwise add
+int dcv_conv_backward_weight_acc(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    t_wgrad_acc = accumulate ? 1 : 0;
+    const int rc = dcv_conv_backward_weight(g, x, xd, dy, dyd, dw, ws, ws_bytes, stream);
+    t_wgrad_acc = 0;
+    return rc;
 }
 
 }  // extern "C"

@@ -68,6 +68,7 @@ _SIGS = {
     "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_data_gated": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
+    "dcv_conv_backward_weight_acc": (C.c_int, [_G, _P, _D, _P, _D, _P, C.c_int, _P, C.c_size_t, _P]),
     "dcv_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "dcv_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),
     "dcv_bn_act_forward_stats": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
@@ -100,6 +101,7 @@ _SIGS = {
     "dcv_cl_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
     "dcv_cl_wgrad_workspace_bytes": (C.c_size_t, [_G, _D, _D]),
     "dcv_cl_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
+    "dcv_cl_conv_backward_weight_acc": (C.c_int, [_G, _P, _D, _P, _D, _P, C.c_int, _P, C.c_size_t, _P]),
     "dcv_cl_from_f32": (C.c_int, [_P, _D, _P, _D, _P]),
     "dcv_cl_to_f32": (C.c_int, [_P, _D, _P, _D, C.c_int, _P]),
     "dcv_cl_elementwise": (C.c_int, [C.c_int, _P, _D, _P, _D, _P, _D, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P]),
@@ -112,7 +114,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 _lock = threading.Lock()
 

@@ -163,6 +163,60 @@ def invalidate_packed_weights(obj) -> None:
             t._dcv_pack = None
 
 
+# --------------------------------------------------------------------------- #
+# parameter-gradient accumulation without torch's elementwise adds (round 5)
+# --------------------------------------------------------------------------- #
+# A parameter's gradient is the sum of several contributions whenever (a) the parameter is used twice in ONE backward — every discriminator parameter: D runs on the real
+# and on the fake batch (trainer.py:299-309) — or (b) its .grad still holds an earlier backward's gradient — the discriminators in the G phase (trainer.py:356 after :319;
+# they are only zeroed at :288-290).  Autograd forms these sums with at::add launches (118 per iteration in round 4's traces: torch's own kernels, built with packed-FP32
+# code the library's build flag cannot reach).  Here the SECOND and later contributions are added by the library's own kernels — the weight gradient's slab
+# reduce (dcv_conv_backward_weight_acc), dcv_axpby for the small BatchNorm / GRU gradients — straight into the tensor that already holds the first, and the backward node
+# returns None for that input: same operands, same order, one rounding = bit-identical sums.
+def _task_id() -> int:
+    return torch._C._current_graph_task_id()
+
+
+def grad_target(p):
+    """Device pointer of the fp32 tensor this backward's NEXT gradient contribution of parameter `p` must be added to; None if this is the first one.
+    (b) an existing .grad; (a) the tensor the first use in the running backward handed to autograd (noted by `note_first`; valid for that graph task only:
+    the engine holds the tensor until the parameter's AccumulateGrad node has run, which is after every use)."""
+    if not isinstance(p, torch.nn.Parameter):
+        return None
+    g = p.grad
+    if g is not None:
+        if g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape:
+            b = getattr(p, "_dcv_bucket", None)      # data parallel: autograd will not visit this parameter's AccumulateGrad node (nothing is returned for it), so
+            b = b() if b is not None else None       # the bucket's "a backward has produced gradients" mark is set here instead of by its post-accumulate hook
+            if b is not None:
+                b.dirty = True
+            return g.data_ptr()
+        return None
+    a = getattr(p, "_dcv_acc", None)
+    if a is not None and a[0] == _task_id() and a[0] >= 0:
+        return a[1]
+    return None
+
+
+def note_first(p, t) -> None:
+    """`t` is the first contribution to p's gradient in the running backward (only its address is kept: an extra reference would make AccumulateGrad clone it)."""
+    if isinstance(p, torch.nn.Parameter) and t is not None and t.is_contiguous():
+        p._dcv_acc = (_task_id(), t.data_ptr())
+
+
+def deliver_small(p, t):
+    """A small fp32 gradient `t` of parameter `p` (BatchNorm weight / bias, GRU weights): added in place by dcv_axpby when a target exists, else returned for autograd."""
+    tgt = grad_target(p)
+    if tgt is None or not t.is_contiguous():
+        note_first(p, t if t.is_contiguous() else None)
+        return t
+    td = dims5(t.reshape(1, -1, 1, 1))
+    check(lib().dcv_axpby(ptr(t), C.byref(td), 1.0, C.c_void_p(tgt), C.byref(td), 1.0, C.c_void_p(tgt), C.byref(td), stream_ptr()), "dcv_axpby (gradient accumulation)")
+    return None
+
+
+_OWN_ACCUMULATION = os.environ.get("DCV_TORCH_GRAD_ADDS") is None      # DCV_TORCH_GRAD_ADDS=1: leave the sums to autograd (A/B, bit-identity test)
+
+
 class _Conv(Function):
     # identity token of the current backward pass: a weight's gradient slot is handed out once per backward (new_backward_epoch() is called by
     # the optimiser wrapper's step(), i.e. between two backwards of the same bucket)
@@ -253,15 +307,23 @@ class _Conv(Function):
             # data parallel: the parameter's slice of its bucket's flat gradient buffer (optim.GradBucket) — the first weight gradient of a
             # backward is written straight into it (autograd adopts the returned tensor as .grad); a second use of the same weight in one
             # backward (D on the real and the fake batch) gets a tensor of its own, which autograd adds
-            slot = getattr(w, "_dcv_grad_slot", None)
-            if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _Conv._epoch[0]:
-                w._dcv_slot_epoch = _Conv._epoch[0]
-                dw = slot.detach()
-            else:
-                dw = _empty(w.shape, w.device)
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
-            check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
+            tgt = grad_target(w) if _OWN_ACCUMULATION else None
+            if tgt is not None:
+                # a later contribution (second use in this backward, or .grad from an earlier backward): the slab reduce adds into the tensor that holds the first
+                check(L.dcv_conv_backward_weight_acc(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
+                      "dcv_conv_backward_weight_acc")
+            else:
+                slot = getattr(w, "_dcv_grad_slot", None)
+                if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _Conv._epoch[0]:
+                    w._dcv_slot_epoch = _Conv._epoch[0]
+                    dw = slot.detach()
+                else:
+                    dw = _empty(w.shape, w.device)
+                check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
+                if _OWN_ACCUMULATION:
+                    note_first(w, dw)
         return dx, dw, None, None, None, None, None, None, None
 
 
@@ -319,6 +381,8 @@ class _BnAct(Function):
         check(L.dcv_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta),
                                     ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()),
               "dcv_bn_act_backward")
+        if _OWN_ACCUMULATION:
+            return dx, deliver_small(gamma, dgb[0]), deliver_small(beta, dgb[1]), None, None, None, None, None, None, None, None, None, None, None
         return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 

@@ -258,12 +258,25 @@ class _ConvCl(Function):
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
             need = L.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd))
             if need == 0:
                 raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + L.dcv_last_error().decode())
             wsp, wsn = _ws("clconv", need, x.device)
-            check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
+            from . import ops as _o
+            tgt = _o.grad_target(w) if _o._OWN_ACCUMULATION else None
+            if tgt is not None:      # a later contribution to this parameter's gradient: added by the slab reduce (ops.grad_target), nothing for autograd to sum
+                check(L.dcv_cl_conv_backward_weight_acc(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
+                      "dcv_cl_conv_backward_weight_acc")
+            else:
+                slot = getattr(w, "_dcv_grad_slot", None)       # data parallel: the parameter's slice of its bucket's flat buffer (optim.GradBucket), as on the fp32 path
+                if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _o._Conv._epoch[0] and _o._OWN_ACCUMULATION:
+                    w._dcv_slot_epoch = _o._Conv._epoch[0]
+                    dw = slot.detach()
+                else:
+                    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+                check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
+                if _o._OWN_ACCUMULATION:
+                    _o.note_first(w, dw)
         return dx, dw, None, None, None, None, None, None
 
 
@@ -313,6 +326,9 @@ class _BnActCl(Function):
         wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
         check(L.dcv_cl_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]),
                                        ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()), "dcv_cl_bn_act_backward")
+        from . import ops as _o
+        if _o._OWN_ACCUMULATION:
+            return dx, _o.deliver_small(gamma, dgb[0]), _o.deliver_small(beta, dgb[1]), None, None, None, None, None, None, None, None, None, None, None
         return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 

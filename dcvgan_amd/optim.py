@@ -146,6 +146,8 @@ class GradBucket:
             if id(p) in have:
                 continue              # already a member (a wrapper built around a bucket that was filled by hand)
             self.params.append(p)
+            import weakref
+            p._dcv_bucket = weakref.ref(self)     # ops.grad_target marks the bucket dirty when it adds a gradient in place (no AccumulateGrad visit, no hook)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._mark))
             self._flat = None         # a new member: the buffer is laid out again at the next gradient (existing .grad slices are copied over)
 

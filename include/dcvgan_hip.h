@@ -63,7 +63,8 @@ typedef struct dcv_conv_geom {
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
-/* ABI version.  2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
+/* ABI version.  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc exist (no struct changed).
+ * 2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
  * A host compares dcv_version() and dcv_abi_struct_sizes() with its own declarations BEFORE the first call that passes a struct
  * (dcvgan_amd/native.py does, and refuses to load on a mismatch): the library cannot see the size of what a pointer points to. */
 int dcv_version(void);
@@ -142,6 +143,13 @@ int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const 
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd,
                              const float* dy, const dcv_dims5* dyd, float* dw,
                              void* ws, size_t ws_bytes, void* stream);
+/* dw = (accumulate ? dw : 0) + corr(x, dy)  (ABI 3).  Replaces the elementwise sums autograd forms when a weight is used twice in one backward (every discriminator
+ * parameter: D on the real and on the fake batch, trainer.py:299-309 -> :319) or when .grad already holds an earlier backward's gradient (the discriminators in the
+ * G phase, trainer.py:356 on top of :319; discriminator.zero_grad() only at :288-290): the slab reduce adds its fixed-order sum to dw — the same two operands and
+ * one rounding as torch's add, so the result is bit-identical. */
+int dcv_conv_backward_weight_acc(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd,
+                                 const float* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                 void* ws, size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm{2,3}d (+ Dropout2d) (+ activation) ------------------------ *
  * Replace nn.BatchNorm2d/3d + nn.Dropout2d + nn.(Leaky)ReLU chains
@@ -282,6 +290,9 @@ int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_
 size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
 int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
                                 void* ws, size_t ws_bytes, void* stream);
+/* dw = (accumulate ? dw : 0) + corr(x, dy)  (ABI 3; as dcv_conv_backward_weight_acc) */
+int dcv_cl_conv_backward_weight_acc(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                    void* ws, size_t ws_bytes, void* stream);
 /* module boundary: fp32 NCDHW (any strides) <-> bf16 channels-last (same shape; padding channels are written as zeros).
  * dcv_cl_to_f32 with accumulate = 1 adds into y (a gradient arriving at an fp32 leaf). */
 int dcv_cl_from_f32(const float* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, void* stream);

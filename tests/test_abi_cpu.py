@@ -55,12 +55,12 @@ def test_integration_md_declares_the_structs_the_library_has(lib):
     sizes = (ctypes.c_size_t * 3)()
     lib.dcv_abi_struct_sizes(sizes)
     assert tuple(sizes) == (ctypes.sizeof(native.Dims5), ctypes.sizeof(native.ConvGeom), ctypes.sizeof(native.WPack))
-    assert lib.dcv_version() == native.ABI_VERSION == 2
-    assert re.search(r"lib\.dcv_version\(\) == 2", text)
+    assert lib.dcv_version() == native.ABI_VERSION == 3
+    assert re.search(r"lib\.dcv_version\(\) == 3", text)
 
 
 def test_version_and_error_channel(lib):
-    assert lib.dcv_version() >= 2
+    assert lib.dcv_version() >= 3
     assert isinstance(lib.dcv_last_error(), bytes)
     assert lib.dcv_launch_count() == 0  # nothing launched on a CPU-only box
 
