@@ -118,6 +118,10 @@ struct ClGatherArgs {
     // BatchNorm sums of the stored outputs, left by the epilogue (conv -> BatchNorm pairs, forward, no activation): stat[stat_row0 + position tile][OCp][2] = {sum, sum of squares}
     float* stat;
     int32_t stat_row0, pad2;
+    // gated data gradient (dcv_cl_conv_backward_data_gated): the (Leaky)ReLU derivative of the layer that PRODUCED this convolution's input, read off that input —
+    // a tensor of the destination's shape and strides — and applied in the epilogue: dx = (accumulate ? dx : 0) + conv^T(dy, w), then dx *= (gate > 0 ? 1 : gate_slope)
+    const __bf16* gate;
+    float gate_slope; int32_t pad3;
 };
 struct ClGatherPack {
     ClGatherArgs c[4];
@@ -425,8 +429,32 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
             const int idx = tid + NT * s, row = idx / GPR, c = idx % GPR;
             const uint32_t vo = rowoff[row];
             const int oc = oc0 + 8 * c;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * EPITCH + c * 16);
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * EPITCH + c * 16);
             const uint32_t v2 = (vo != 0xffffffffu && oc < a.y_c) ? vo + (uint32_t)(2 * oc) : 0xffffffffu;
+            if (accum || a.gate) {
+                // dx += ... and / or the producer's activation derivative, on the row-order granules (the staged value is the bf16 rounding of the accumulator: the sum
+                // round(round(acc) + old) is what adding two separately stored bf16 gradients gives)
+                float f[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { f[2 * q] = __builtin_bit_cast(float, v[q] << 16); f[2 * q + 1] = __builtin_bit_cast(float, v[q] & 0xffff0000u); }
+                if (accum) {
+                    const u32x4 old = __builtin_amdgcn_raw_buffer_load_b128(yrs, v2, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { f[2 * q] += __builtin_bit_cast(float, old[q] << 16); f[2 * q + 1] += __builtin_bit_cast(float, old[q] & 0xffff0000u); }
+                }
+                if (a.gate) {
+                    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.gate), 0, a.y_bytes, 0x00020000);
+                    const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(grs, v2, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!(__builtin_bit_cast(float, gv[q] << 16) > 0.f)) f[2 * q] *= a.gate_slope;
+                        if (!(__builtin_bit_cast(float, gv[q] & 0xffff0000u) > 0.f)) f[2 * q + 1] *= a.gate_slope;
+                    }
+                }
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const f32x2_ t = {f[2 * q], f[2 * q + 1]}; v[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2)); }
+            }
             __builtin_amdgcn_raw_buffer_store_b128(v, yrs, v2, 0, 0);
         }
     } else {
@@ -1456,7 +1484,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
 // *nparts stays 0 where the form does not produce them (thin destinations) and the caller's BatchNorm op takes its own statistics.
 static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, const dcv_dims5* xd, const void* packed, void* dst_p, const dcv_dims5* yd,
                        int act, float slope, int accumulate, void* ws, size_t ws_bytes, void* stream,
-                       float* stat = nullptr, size_t stat_bytes = 0, int* nparts = nullptr, int* pitch = nullptr) {
+                       float* stat = nullptr, size_t stat_bytes = 0, int* nparts = nullptr, int* pitch = nullptr, const void* gate = nullptr, float gate_slope = 0.f) {
     if (nparts) *nparts = 0;
     if (pitch) *pitch = 0;
     if (!g || !xd || !yd || !src_p || !packed || !dst_p) return fail(DCV_EINVAL, "cl conv: null pointer");
@@ -1466,6 +1494,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     const dcv_dims5& src = (which == 0) ? *xd : *yd;
     const dcv_dims5& dst = (which == 0) ? *yd : *xd;
     if ((rc = cl_check_tensor(src, "cl conv source")) != DCV_OK || (rc = cl_check_tensor(dst, "cl conv destination")) != DCV_OK) return rc;
+    if (gate && (cl_thin_out(pl, g) || cl_thin(pl.RC))) return fail(DCV_EUNSUPPORTED, "cl conv: no gated epilogue in the thin forms");
     if (cl_thin_out(pl, g)) return cl_conv_thin_out(which, g, pl, src_p, src, packed, dst_p, dst, act, slope, accumulate, ws, ws_bytes, static_cast<hipStream_t>(stream));
     const bool thin = cl_thin(pl.RC);
     const int Cp = cl_cp(pl.RC);
@@ -1539,7 +1568,11 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
         a.act = act; a.slope = slope; a.accumulate = accumulate;
         // 16-byte row-order stores need whole 8-channel groups at 16-byte-aligned pixel bases (pitches are multiples of 8 elements: cl_check_tensor)
         static const bool no_coalesce = getenv("DCV_CL_DIRECT_EPILOGUE") != nullptr;      // A/B only
-        a.coalesce = (!accumulate && ocs % 8 == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && !no_coalesce) ? 1 : 0;
+        a.coalesce = (ocs % 8 == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && !no_coalesce) ? 1 : 0;
+        if (gate) {
+            if (!a.coalesce) return fail(DCV_EUNSUPPORTED, "cl conv: the gated epilogue needs the row-order store form");
+            a.gate = static_cast<const __bf16*>(gate); a.gate_slope = gate_slope;
+        }
         a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
         for (int t = 0; t < T; ++t) {
             const int ud = t / (c.t[1].n * c.t[2].n), uh = (t / c.t[2].n) % c.t[1].n, uw = t % c.t[2].n;
@@ -1601,6 +1634,19 @@ int dcv_cl_conv_forward_stats(const dcv_conv_geom* g, const void* x, const dcv_d
 int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
                               int accumulate, void* ws, size_t ws_bytes, void* stream) {
     return cl_conv_run(1, g, dy, dxd, packed, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream);
+}
+
+// backward_data followed by the (Leaky)ReLU derivative of the layer that produced this convolution's input, read off that input (`xg`: dx's shape AND strides):
+// dx = (accumulate ? dx : 0) + conv^T(dy, w); dx *= (xg > 0 ? 1 : slope).  Replaces the separate derivative pass of a conv + LeakyReLU pair whose output feeds this
+// convolution (Inconv -> DownBlock 0, generator.py:173-176,203-207), as dcv_conv_backward_data_gated does on the fp32 path.  DCV_EUNSUPPORTED before any launch
+// where the form has no such epilogue (thin operands, unaligned destinations): the caller then runs the two steps separately.
+int dcv_cl_conv_backward_data_gated(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
+                                    int accumulate, const void* xg, const dcv_dims5* xgd, int act, float slope, void* ws, size_t ws_bytes, void* stream) {
+    if (!xg || !xgd || !dxd) return fail(DCV_EINVAL, "cl_conv_backward_data_gated: null pointer");
+    if (act != DCV_ACT_LEAKY) return fail(DCV_EUNSUPPORTED, "cl_conv_backward_data_gated: (Leaky)ReLU only");
+    if (!same_shape(*xgd, *dxd) || xgd->sn != dxd->sn || xgd->sc != dxd->sc || xgd->sd != dxd->sd || xgd->sh != dxd->sh || xgd->sw != dxd->sw)
+        return fail(DCV_EINVAL, "cl_conv_backward_data_gated: the gate tensor must have dx's shape and strides");
+    return cl_conv_run(1, g, dy, dxd, packed, dx, dyd, DCV_ACT_NONE, 0.f, accumulate, ws, ws_bytes, stream, nullptr, 0, nullptr, nullptr, xg, slope);
 }
 
 size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y) {

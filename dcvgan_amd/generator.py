@@ -194,7 +194,7 @@ class ColorVideoGenerator(nn.Module):
         size = [x.shape[2] >> k for k in range(7)]
         bufs = [ops_cl.ConcatBuffer(nb, ups[5 - k], widths[k], (size[k], size[k]), x.device) for k in range(6)]
         bufs.append(ops_cl.ConcatBuffer(nb, widths[6], self.dim_z, (size[6], size[6]), x.device))
-        skips = [self.inconv(ops_cl.from_f32(x), rng, out=bufs[0].second)]
+        skips = [self.inconv(ops_cl.from_f32(x), rng, out=bufs[0].second, act_slot=bufs[0].slot)]
         for k, blk in enumerate(self.down_blocks):
             dst = bufs[k + 1].second if k + 1 < 6 else bufs[6].first
             skips.append(blk(skips[-1], rng, out=dst, grad_slot=bufs[k].slot))      # skips[k] lives in bufs[k].second

@@ -86,7 +86,8 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             fused = _act_of(nxt) if nxt is not None else None
             last = i + (2 if fused is not None else 1) >= n
             box = [] if (fused is None and isinstance(nxt, _BNS) and nxt.training and _FUSE_BN_STATS) else None
-            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None, grad_slot=grad_slot if i == 0 else None, bn_stats=box)
+            x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None, grad_slot=grad_slot if i == 0 else None, bn_stats=box,
+                            act_slot=act_slot if (last and fused is not None) else None)
             pending = box[0] if box else None
             i += 2 if fused is not None else 1
         elif isinstance(layer, _CONVS):

@@ -100,6 +100,7 @@ _SIGS = {
     "dcv_cl_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t, _P]),
     "dcv_cl_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
     "dcv_cl_wgrad_workspace_bytes": (C.c_size_t, [_G, _D, _D]),
+    "dcv_cl_conv_backward_data_gated": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
     "dcv_cl_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
     "dcv_cl_conv_backward_weight_acc": (C.c_int, [_G, _P, _D, _P, _D, _P, C.c_int, _P, C.c_size_t, _P]),
     "dcv_cl_from_f32": (C.c_int, [_P, _D, _P, _D, _P]),

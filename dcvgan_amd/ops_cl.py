@@ -205,9 +205,13 @@ def _packed(w: torch.Tensor, which: int, g: ConvGeom, xd, yd, key_dims):
 
 class _ConvCl(Function):
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, grad_slot=None, bn_stats=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, grad_slot=None, bn_stats=None, act_slot=None):
         _req(x, "conv input"); N._require(w, "conv weight")
         ctx.grad_slot = grad_slot
+        # this conv + (Leaky)ReLU writes a skip tensor (second slice of a concat buffer): the consumer's data gradient may apply the derivative (ops.GradSlot)
+        ctx.act_slot = act_slot if (act_slot is not None and act == ACT_LEAKY) else None
+        if ctx.act_slot is not None:
+            ctx.act_slot.act, ctx.act_slot.act_applied = (act, slope), False
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
         shape = _out_shape(g, x)
@@ -238,7 +242,10 @@ class _ConvCl(Function):
         g = ctx.g
         L = lib()
         dy = as_cl(dy)
-        if ctx.act != ACT_NONE:
+        fused_away = ctx.act_slot is not None and ctx.act_slot.act_applied      # the consumer's data gradient already applied act' (gated epilogue)
+        if ctx.act_slot is not None:
+            ctx.act_slot.act_applied = False
+        if ctx.act != ACT_NONE and not fused_away:
             dy = _ew(3 if ctx.act == ACT_LEAKY else 4, dy, y, ctx.slope)
         xd, dyd = dims5(x), dims5(dy)
         dx = dw = None
@@ -253,8 +260,20 @@ class _ConvCl(Function):
             dxd = dims5(dx)
             pk = _packed(w, 1, g, dxd, dyd, tuple(x.shape))
             wsp, wsn = _ws("clconv", L.dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1), x.device)
-            check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), int(into is not None), wsp, wsn, stream_ptr()),
-                  "dcv_cl_conv_backward_data")
+            rc = N.DCV_EUNSUPPORTED
+            from . import ops as _o2
+            if into is not None and slot.act is not None and _o2._GATED_DGRAD and tuple(x.stride()) == tuple(into.stride()):
+                # ... and the derivative of the activation that produced x, read off x, in the same epilogue (Inconv -> DownBlock 0)
+                xgd = dims5(x)
+                rc = L.dcv_cl_conv_backward_data_gated(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 1, ptr(x), C.byref(xgd),
+                                                       slot.act[0], slot.act[1], wsp, wsn, stream_ptr())
+                if rc == 0:
+                    slot.act_applied = True
+                elif rc != N.DCV_EUNSUPPORTED:
+                    check(rc, "dcv_cl_conv_backward_data_gated")
+            if rc == N.DCV_EUNSUPPORTED:
+                check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), int(into is not None), wsp, wsn, stream_ptr()),
+                      "dcv_cl_conv_backward_data")
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:
@@ -277,14 +296,14 @@ class _ConvCl(Function):
                 check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
                 if _o._OWN_ACCUMULATION:
                     _o.note_first(w, dw)
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, grad_slot=None, bn_stats=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, grad_slot=None, bn_stats=None, act_slot=None):
     """y = act(conv(x, w)) on CL16 tensors; fp32 weights in torch layout; `out`: destination view (a channel slice of a concat buffer);
     `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection); `bn_stats`: a list that receives (buffer, nparts, pitch) when the
     epilogue produced the following BatchNorm's sums (conv -> BatchNorm pairs in training mode, no activation in between)."""
-    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out), grad_slot, bn_stats)
+    return _ConvCl.apply(x, w, g, act, float(slope), None if out is None else _Out(out), grad_slot, bn_stats, act_slot)
 
 
 # --------------------------------------------------------------------------- #

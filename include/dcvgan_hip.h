@@ -287,6 +287,11 @@ int dcv_cl_conv_forward_stats(const dcv_conv_geom* g, const void* x, const dcv_d
                               float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream);
 int dcv_cl_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
                               int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* backward_data + the (Leaky)ReLU derivative of the layer that produced this convolution's input, read off that input `xg` (dx's shape and strides), in one epilogue
+ * (ABI 3): dx = (accumulate ? dx : 0) + conv^T(dy, w); dx *= (xg > 0 ? 1 : slope).  The bf16 counterpart of dcv_conv_backward_data_gated (Inconv -> DownBlock 0,
+ * generator.py:173-176,203-207).  DCV_EUNSUPPORTED before any launch where the form has no such epilogue. */
+int dcv_cl_conv_backward_data_gated(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd,
+                                    int accumulate, const void* xg, const dcv_dims5* xgd, int act, float slope, void* ws, size_t ws_bytes, void* stream);
 size_t dcv_cl_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
 int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
                                 void* ws, size_t ws_bytes, void* stream);

@@ -400,3 +400,41 @@ def test_bn_sums_from_the_conv_epilogue_cl16(case):
     assert n1 == n0 == 1
     assert rel(rm1, rm0) < 1e-6 and rel(rv1, rv0) < 1e-6, (rel(rm1, rm0), rel(rv1, rv0))
     assert rel(z1, z0) < 1e-4 and float((z1 != z0).float().mean()) < 2e-2, (rel(z1, z0), float((z1 != z0).float().mean()))
+
+
+def test_gated_skip_gradient_cl16():
+    """Inconv -> DownBlock 0 on the bf16 path: DownBlock 0's data gradient accumulates into the concat buffer's gradient slice AND applies Inconv's LeakyReLU
+    derivative in its epilogue (dcv_cl_conv_backward_data_gated; ops.GradSlot) — against the three-step form (accumulate, then a derivative pass).  The fused form
+    rounds once less, so the two agree to bf16 rounding, not bit for bit."""
+    from dcvgan_amd import native, ops, ops_cl, trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    native.lib()
+    cfg = CONFIGS["isogd-depth"].scaled(batchsize=2, width_div=2)
+    x = (torch.rand(6, 1, 64, 64, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(DEV)
+
+    def run(gated):
+        old = ops._GATED_DGRAD
+        ops._GATED_DGRAD = gated
+        ops_cl.enable(True)
+        try:
+            torch.manual_seed(9)
+            cgen = trainer.build_models(cfg, DEV)["cgen"]
+            cgen._rng = PhiloxRng(3)
+            cgen.train()
+            n0 = native.launch_count()
+            z = torch.randn(6, cgen.dim_z, 1, 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+            y = cgen(x, z)
+            (y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum().backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in cgen.named_parameters()}, native.launch_count() - n0
+        finally:
+            ops._GATED_DGRAD = old
+            ops_cl.enable(False)
+
+    ga, la = run(True)
+    gb, lb = run(False)
+    assert la == lb - 1, (la, lb)                      # exactly the derivative pass is gone
+    for n in ga:
+        assert rel(ga[n], gb[n]) < 2e-2, (n, rel(ga[n], gb[n]))
+    assert rel(ga["inconv.main.0.weight"], gb["inconv.main.0.weight"]) < 1e-2
