@@ -24,8 +24,15 @@ for f in conv_mfma elementwise conv_cl16 cl_elementwise; do
     pids+=($!)
   fi
 done
+# the 16-bit channels-last path a second time with fp16 as its element type (-DDCV_CL_FP16: entry points dcv_clf16_*; BASELINE configs[4] names fp16 MFMA)
+for f in conv_cl16 cl_elementwise; do
+  if [ ! -f "$OBJ/${f}_f16.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/${f}_f16.o" ] || [ "$HERE/dcv_common.h" -nt "$OBJ/${f}_f16.o" ] || [ "$ROOT/include/dcvgan_hip.h" -nt "$OBJ/${f}_f16.o" ]; then
+    hipcc $FLAGS -DDCV_CL_FP16 ${EXTRA_HIPCC_FLAGS:-} -c "$HERE/$f.hip" -o "$OBJ/${f}_f16.o" 2> >(grep -v "not a recognized feature for this target" >&2) &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || exit 1; }; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/conv_mfma.o" "$OBJ/elementwise.o" "$OBJ/conv_cl16.o" "$OBJ/cl_elementwise.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/conv_mfma.o" "$OBJ/elementwise.o" "$OBJ/conv_cl16.o" "$OBJ/cl_elementwise.o" "$OBJ/conv_cl16_f16.o" "$OBJ/cl_elementwise_f16.o"
 # The flag above is only worth something if it took effect (its "not a recognized feature" host-pass message is filtered, and a hipcc that dropped or renamed
 # the feature would bring the packed instructions back silently): disassemble the device code of the library just linked and fail on any packed-FP32 arithmetic.
 OBJDUMP=/opt/rocm/lib/llvm/bin/llvm-objdump

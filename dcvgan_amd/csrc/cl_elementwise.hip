@@ -4,12 +4,24 @@
 // 16-byte group of 8 channels of a pixel, so a wave reads and writes whole 128-byte lines when C >= 64.  Statistics and parameters are fp32.
 #include "dcv_common.h"
 
+#ifdef DCV_CL_FP16      // the fp16 build of this file: same code, element type cl_h = _Float16, entry points dcv_clf16_*
+#define dcv_cl_from_f32 dcv_clf16_from_f32
+#define dcv_cl_to_f32 dcv_clf16_to_f32
+#define dcv_cl_elementwise dcv_clf16_elementwise
+#define dcv_cl_bn_workspace_bytes dcv_clf16_bn_workspace_bytes
+#define dcv_cl_bn_act_forward dcv_clf16_bn_act_forward
+#define dcv_cl_bn_act_forward_stats dcv_clf16_bn_act_forward_stats
+#define dcv_cl_bn_act_backward dcv_clf16_bn_act_backward
+#define cl_bn_finalize_stat_kernel cl_bn_finalize_stat_kernel_f16      // (a kernel defined at file scope inside the extern "C" block)
+#endif
+
 #include <algorithm>
 
 namespace dcv {
+#ifdef DCV_CL_FP16
+inline namespace clf16 {
+#endif
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 struct ClView {          // one sample-linear bf16 tensor
@@ -23,17 +35,17 @@ struct ClShape {
 
 __device__ __forceinline__ void cl_unpack(const u32x4 w, float (&v)[8]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { v[2 * q] = __builtin_bit_cast(float, w[q] << 16); v[2 * q + 1] = __builtin_bit_cast(float, w[q] & 0xffff0000u); }
+    for (int q = 0; q < 4; ++q) { v[2 * q] = cl_lo(w[q]); v[2 * q + 1] = cl_hi(w[q]); }
 }
 __device__ __forceinline__ u32x4 cl_pack(const float (&v)[8]) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     u32x4 w;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; w[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2)); }
+    for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; w[q] = cl_pack2(f[0], f[1]); }
     return w;
 }
-__device__ __forceinline__ u32x4 cl_ld(const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ void cl_st(__bf16* p, const u32x4 w) { *reinterpret_cast<u32x4*>(p) = w; }
+__device__ __forceinline__ u32x4 cl_ld(const cl_h* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void cl_st(cl_h* p, const u32x4 w) { *reinterpret_cast<u32x4*>(p) = w; }
 
 // work item i -> (n, pixel, group): group fastest
 __device__ __forceinline__ void cl_decode(const ClShape& s, int64_t i, int& n, int& pix, int& g) {
@@ -45,7 +57,7 @@ __device__ __forceinline__ void cl_decode(const ClShape& s, int64_t i, int& n, i
 
 // ---- fp32 NCDHW (any strides) <-> CL16 ------------------------------------------------------
 struct ClCvtArgs {
-    const float* f; __bf16* b;
+    const float* f; cl_h* b;
     int64_t f_sn, f_sc; int32_t f_sd, f_sh, f_sw;
     int32_t D, H, W, C, Cpad;       // Cpad: channels written on the CL16 side (zeros past C)
     int64_t b_sn; int32_t b_pitch;
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(256) void cl_to_f32_kernel(const ClCvtArgs a, int a
 // kind 0: y = x (copy)            1: y = a x + b z           2: y = x + sigma N(0,1)        3: dx = dy * lrelu'(y; slope)   4: dx = dy * (1 - y^2)
 // 5: y = lrelu(x)                 6: y = tanh(x)
 struct ClEwArgs {
-    const __bf16* x; const __bf16* z; __bf16* y;
+    const cl_h* x; const cl_h* z; cl_h* y;
     ClView xv, zv, yv;
     ClShape s;
     int64_t total;
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void cl_ew_kernel(const ClEwArgs a) {
 // Block = PB pixels x G groups (G = C / 8 <= 128): thread (p, g) walks pixels p, p + PB * gridDim.x, ...; per-thread fp32 sums of its 8 channels
 // (bounded runs: at most `run` terms, then folded into doubles), block-combined through LDS in a fixed order, written as partial[block][C][NV].
 struct ClBnArgs {
-    const __bf16* x; const __bf16* dy; __bf16* y;
+    const cl_h* x; const cl_h* dy; cl_h* y;
     ClView xv, dyv, yv;
     int32_t N, C, PIX, G;
     FastDiv div_pix;
@@ -493,6 +505,9 @@ static ClShape cl_shape(const dcv_dims5& d) {
     return s;
 }
 
+#ifdef DCV_CL_FP16
+}  // inline namespace clf16
+#endif
 }  // namespace dcv
 
 using namespace dcv;
@@ -520,7 +535,7 @@ int dcv_cl_from_f32(const float* x, const dcv_dims5* xd, void* y, const dcv_dims
     int rc = cl_cvt_args(xd, yd, &a, "cl_from_f32");
     if (rc != DCV_OK) return rc;
     if (!x || !y) return fail(DCV_EINVAL, "cl_from_f32: null pointer");
-    a.f = x; a.b = static_cast<__bf16*>(y);
+    a.f = x; a.b = static_cast<cl_h*>(y);
     if (a.total == 0) return DCV_OK;
     hipLaunchKernelGGL(cl_from_f32_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     DCV_LAUNCH_CHECK();
@@ -531,7 +546,7 @@ int dcv_cl_to_f32(const void* x, const dcv_dims5* xd, float* y, const dcv_dims5*
     int rc = cl_cvt_args(yd, xd, &a, "cl_to_f32");
     if (rc != DCV_OK) return rc;
     if (!x || !y) return fail(DCV_EINVAL, "cl_to_f32: null pointer");
-    a.f = y; a.b = const_cast<__bf16*>(static_cast<const __bf16*>(x));
+    a.f = y; a.b = const_cast<cl_h*>(static_cast<const cl_h*>(x));
     if (a.total == 0) return DCV_OK;
     hipLaunchKernelGGL(cl_to_f32_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, accumulate);
     DCV_LAUNCH_CHECK();
@@ -548,7 +563,7 @@ int dcv_cl_elementwise(int kind, const void* x, const dcv_dims5* xd, const void*
     memset(&a, 0, sizeof(a));
     if (!same_shape(*xd, *yd) || (two && !same_shape(*xd, *zd))) return fail(DCV_EINVAL, "cl_elementwise: shapes differ");
     if (!cl_view(*xd, &a.xv) || !cl_view(*yd, &a.yv) || (two && !cl_view(*zd, &a.zv))) return fail(DCV_EINVAL, "cl_elementwise: operands must be sample-linear channels-last");
-    a.x = static_cast<const __bf16*>(x); a.z = static_cast<const __bf16*>(z); a.y = static_cast<__bf16*>(y);
+    a.x = static_cast<const cl_h*>(x); a.z = static_cast<const cl_h*>(z); a.y = static_cast<cl_h*>(y);
     a.s = cl_shape(*xd);
     a.total = (int64_t)a.s.N * a.s.PIX * a.s.G;
     a.kind = kind; a.a = a_; a.b = b_; a.seed = seed; a.offset = offset;
@@ -651,7 +666,7 @@ static int cl_bn_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)1024 * a.C * 2 * sizeof(double));
-    a.x = static_cast<const __bf16*>(x); a.y = static_cast<__bf16*>(y); a.partial = partial; a.mask = mask; a.act = act; a.slope = slope;
+    a.x = static_cast<const cl_h*>(x); a.y = static_cast<cl_h*>(y); a.partial = partial; a.mask = mask; a.act = act; a.slope = slope;
     a.scale = coef; a.shift = coef + a.C;
     const int cb = (a.C + 63) / 64;
     if (training && stat) {
@@ -688,7 +703,7 @@ int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* partial = static_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)1024 * a.C * 2 * sizeof(double));
-    a.x = static_cast<const __bf16*>(x); a.dy = static_cast<const __bf16*>(dy); a.y = static_cast<__bf16*>(dx); a.partial = partial; a.mask = mask; a.act = act; a.slope = slope;
+    a.x = static_cast<const cl_h*>(x); a.dy = static_cast<const cl_h*>(dy); a.y = static_cast<cl_h*>(dx); a.partial = partial; a.mask = mask; a.act = act; a.slope = slope;
     a.scale = coef; a.shift = coef + a.C;
     const int cb = (a.C + 63) / 64;
     a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.invstd = save_invstd;

@@ -18,6 +18,21 @@
 //      [position][channel] LDS images with the transposing read ds_read_b64_tr_b16.
 #include "dcv_common.h"
 
+#ifdef DCV_CL_FP16      // the fp16 build of this file: same code, element type cl_h = _Float16, entry points dcv_clf16_*
+#define dcv_cl_debug_read_stamps dcv_clf16_debug_read_stamps
+#define dcv_cl_packed_bytes dcv_clf16_packed_bytes
+#define dcv_cl_conv_workspace_bytes dcv_clf16_conv_workspace_bytes
+#define dcv_cl_pack_weights dcv_clf16_pack_weights
+#define dcv_cl_conv_forward dcv_clf16_conv_forward
+#define dcv_cl_conv_stats_bytes dcv_clf16_conv_stats_bytes
+#define dcv_cl_conv_forward_stats dcv_clf16_conv_forward_stats
+#define dcv_cl_conv_backward_data dcv_clf16_conv_backward_data
+#define dcv_cl_conv_backward_data_gated dcv_clf16_conv_backward_data_gated
+#define dcv_cl_wgrad_workspace_bytes dcv_clf16_wgrad_workspace_bytes
+#define dcv_cl_conv_backward_weight dcv_clf16_conv_backward_weight
+#define dcv_cl_conv_backward_weight_acc dcv_clf16_conv_backward_weight_acc
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -25,18 +40,18 @@
 #include <vector>
 
 namespace dcv {
+extern thread_local char g_last_kernel[160];
+#ifdef DCV_CL_FP16
+inline namespace clf16 {
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-extern thread_local char g_last_kernel[160];
 
 // --------------------------------------------------------------------------- //
 // geometry: one "class" = the output positions that share a tap set (all of them for a direct gather; one stride-parity class
@@ -99,9 +114,9 @@ static inline int cl_cp(int C) { return cl_thin(C) ? 8 : (C + 31) / 32 * 32; }
 // gather GEMM
 // --------------------------------------------------------------------------- //
 struct ClGatherArgs {
-    const __bf16* x;
-    __bf16* y;
-    const __bf16* wp;            // [step][OCp][32] bf16
+    const cl_h* x;
+    cl_h* y;
+    const cl_h* wp;            // [step][OCp][32] bf16
     int32_t M, OCp, nsteps, T;   // positions, padded output channels (multiple of the tile's), 32-deep K steps, taps
     int32_t cblk, y_c;           // 32-channel blocks per tap (0 = thin); channels to store (destination channels, multiple of 4)
     int32_t x_cmax, coalesce;    // bytes of one pixel's own channels, rounded up to a granule (granules past them read as zeros); epilogue through LDS (16-byte row-order stores)
@@ -120,7 +135,7 @@ struct ClGatherArgs {
     int32_t stat_row0, pad2;
     // gated data gradient (dcv_cl_conv_backward_data_gated): the (Leaky)ReLU derivative of the layer that PRODUCED this convolution's input, read off that input —
     // a tensor of the destination's shape and strides — and applied in the epilogue: dx = (accumulate ? dx : 0) + conv^T(dy, w), then dx *= (gate > 0 ? 1 : gate_slope)
-    const __bf16* gate;
+    const cl_h* gate;
     float gate_slope; int32_t pad3;
 };
 struct ClGatherPack {
@@ -200,8 +215,8 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
     const int woc = wave / WM, wm = wave % WM;
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wp), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.wp), 0, 0x80000000u, 0x00020000);
     // thin operands: a lane's granule is one TAP of the step, so the tap offset is per lane: table in LDS (one array: see the LDS-DMA tracking
     // note in conv_mfma.hip), read one step ahead of its use
     const int32_t* toff_l = reinterpret_cast<const int32_t*>(smem + NS * STAGE);
@@ -354,22 +369,22 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
         const char* sb = smem + buf * STAGE;
         nbuf = buf;
         buf = buf + 1 == NS ? 0 : buf + 1;
-        bf16x8 a8[TOC][2], b8[TM][2];
+        cl_h8 a8[TOC][2], b8[TM][2];
 #pragma unroll
         for (int i = 0; i < TOC; ++i)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) a8[i][s] = *reinterpret_cast<const bf16x8*>(sb + aoff[i][s]);
+            for (int s = 0; s < 2; ++s) a8[i][s] = *reinterpret_cast<const cl_h8*>(sb + aoff[i][s]);
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) b8[j][s] = *reinterpret_cast<const bf16x8*>(sb + boff[j][s]);
+            for (int s = 0; s < 2; ++s) b8[j][s] = *reinterpret_cast<const cl_h8*>(sb + boff[j][s]);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int i = 0; i < TOC; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i][s], b8[j][s], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TM; ++j) acc[i][j] = CL_MFMA(a8[i][s], b8[j][s], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
 #ifdef DCV_CL_STAMP
         { const unsigned long long t3_ = CL_T(); ts_wait += t1_ - t0_; ts_issue += t2_ - t1_; ts_mma += t3_ - t2_; }
@@ -417,8 +432,8 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
                     typedef float f32x2_ __attribute__((ext_vector_type(2)));
                     const f32x2_ p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
                     u32x2 o;
-                    o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
-                    o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                    o[0] = cl_pack2(p0[0], p0[1]);
+                    o[1] = cl_pack2(p1[0], p1[1]);
                     *reinterpret_cast<u32x2*>(smem + row * EPITCH + ocl * 2) = o;
                 }
         }
@@ -436,24 +451,24 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
                 // round(round(acc) + old) is what adding two separately stored bf16 gradients gives)
                 float f[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { f[2 * q] = __builtin_bit_cast(float, v[q] << 16); f[2 * q + 1] = __builtin_bit_cast(float, v[q] & 0xffff0000u); }
+                for (int q = 0; q < 4; ++q) { f[2 * q] = cl_lo(v[q]); f[2 * q + 1] = cl_hi(v[q]); }
                 if (accum) {
                     const u32x4 old = __builtin_amdgcn_raw_buffer_load_b128(yrs, v2, 0, 0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { f[2 * q] += __builtin_bit_cast(float, old[q] << 16); f[2 * q + 1] += __builtin_bit_cast(float, old[q] & 0xffff0000u); }
+                    for (int q = 0; q < 4; ++q) { f[2 * q] += cl_lo(old[q]); f[2 * q + 1] += cl_hi(old[q]); }
                 }
                 if (a.gate) {
-                    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.gate), 0, a.y_bytes, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.gate), 0, a.y_bytes, 0x00020000);
                     const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(grs, v2, 0, 0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (!(__builtin_bit_cast(float, gv[q] << 16) > 0.f)) f[2 * q] *= a.gate_slope;
-                        if (!(__builtin_bit_cast(float, gv[q] & 0xffff0000u) > 0.f)) f[2 * q + 1] *= a.gate_slope;
+                        if (!(cl_lo(gv[q]) > 0.f)) f[2 * q] *= a.gate_slope;
+                        if (!(cl_hi(gv[q]) > 0.f)) f[2 * q + 1] *= a.gate_slope;
                     }
                 }
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const f32x2_ t = {f[2 * q], f[2 * q + 1]}; v[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t, bf16x2)); }
+                for (int q = 0; q < 4; ++q) { const f32x2_ t = {f[2 * q], f[2 * q + 1]}; v[q] = cl_pack2(t[0], t[1]); }
             }
             __builtin_amdgcn_raw_buffer_store_b128(v, yrs, v2, 0, 0);
         }
@@ -483,16 +498,16 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 if (accum) {
                     const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(yrs, v2, 0, 0);
-                    v[0] += __builtin_bit_cast(float, old[0] << 16); v[1] += __builtin_bit_cast(float, old[0] & 0xffff0000u);
-                    v[2] += __builtin_bit_cast(float, old[1] << 16); v[3] += __builtin_bit_cast(float, old[1] & 0xffff0000u);
+                    v[0] += cl_lo(old[0]); v[1] += cl_hi(old[0]);
+                    v[2] += cl_lo(old[1]); v[3] += cl_hi(old[1]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = cl_act(v[e], act, slope);
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
                 const f32x2_ p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
                 u32x2 o;
-                o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
-                o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                o[0] = cl_pack2(p0[0], p0[1]);
+                o[1] = cl_pack2(p1[0], p1[1]);
                 __builtin_amdgcn_raw_buffer_store_b64(o, yrs, v2, 0, 0);
             }
     }
@@ -509,7 +524,7 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
             for (int r = 0; r < 16; ++r) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < TM; ++j) { const float v = (float)(__bf16)acc[i][j][r]; s1 += v; s2 += v * v; }
+                for (int j = 0; j < TM; ++j) { const float v = cl_round(acc[i][j][r]); s1 += v; s2 += v * v; }
                 s1 = cl_half_wave_sum(s1);
                 s2 = cl_half_wave_sum(s2);
                 if (l31 == 31) {
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
 
 // Wp[cls][step][OCp][32]: thick: step = tap * cblk + cb, k = channel cb * 32 + kk;  thin: step covers taps 4 step .. 4 step + 3, k = (tap & 3) * 8 + channel
 struct ClPackArgs {
-    __bf16* wp[4];
+    cl_h* wp[4];
     int32_t nsteps[4], T[4];
     int32_t kidx[4][64];      // filter index (kd * KH + kh) * KW + kw of tap t
     int32_t ncls, OC, OCp, C, cblk;   // cblk = 0: thin
@@ -557,7 +572,7 @@ __global__ __launch_bounds__(256) void cl_pack_kernel(const float* __restrict__ 
     else { tap = step / pa.cblk; c = (step % pa.cblk) * 32 + kk; }
     float v = 0.f;
     if (oc < pa.OC && c < pa.C && tap < pa.T[cls]) v = w[(int64_t)oc * pa.ws_o + (int64_t)c * pa.ws_r + pa.kidx[cls][tap]];
-    pa.wp[cls][i] = (__bf16)v;
+    pa.wp[cls][i] = (cl_h)v;
 }
 
 // --------------------------------------------------------------------------- //
@@ -611,8 +626,8 @@ __global__ __launch_bounds__(256) void cl_postab_kernel(const ClPosArgs a) {
 }
 
 struct ClWgradArgs {
-    const __bf16* d;
-    const __bf16* g;
+    const cl_h* d;
+    const cl_h* g;
     const ClPosEntry* tab;
     float* slab;                 // [split][tile][128][128]
     int32_t M, chunk;            // positions; positions per split (multiple of 32)
@@ -656,8 +671,8 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
     const int m_end = min(a.M, m_begin + a.chunk);
     const int nst = m_end > m_begin ? (m_end - m_begin + 31) / 32 : 0;
 
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.d), 0, a.d_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.g), 0, a.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.d), 0, a.d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.g), 0, a.g_bytes, 0x00020000);
 
     // staging roles: granule g = tid + 256 s -> row g >> 4 (position of the step), physical chunk g & 15, logical chunk ^ f(row)
     uint32_t dvo[2];
@@ -741,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[2], bfr[2];
+                cl_h8 af[2], bfr[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + fa[i][kk][0]));
@@ -751,13 +766,13 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    af[i] = __builtin_bit_cast(bf16x8, av);
-                    bfr[i] = __builtin_bit_cast(bf16x8, bv);
+                    af[i] = __builtin_bit_cast(cl_h8, av);
+                    bfr[i] = __builtin_bit_cast(cl_h8, bv);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = CL_MFMA(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
             e0 = n0; e1 = n1;
         }
@@ -849,7 +864,7 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_slab_kernel(const ClWgrad
 }
 
 struct ClPackThinArgs {
-    __bf16* wp;
+    cl_h* wp;
     int32_t nsteps, OCg, OCgp, C, OC, T;   // K steps (C / 32 blocks), T * OC GEMM columns, padded, source channels, real output channels, taps
     int64_t ws_o, ws_r;
 };
@@ -864,12 +879,12 @@ __global__ __launch_bounds__(256) void cl_pack_thin_kernel(const float* __restri
         const int t = col / pa.OC, oc = col - t * pa.OC;
         v = w[(int64_t)oc * pa.ws_o + (int64_t)c * pa.ws_r + t];
     }
-    pa.wp[i] = (__bf16)v;
+    pa.wp[i] = (cl_h)v;
 }
 
 struct ClCol2imArgs {
-    const __bf16* z;
-    __bf16* y;
+    const cl_h* z;
+    cl_h* y;
     int32_t OC, zpitch, T, scatter;          // scatter: src = (dst + p - k) / s when divisible; else src = dst * s - p + k
     int32_t k[3], s[3], p[3], sext[3];       // filter, stride, padding, source extents
     int32_t dext[3], act;
@@ -900,20 +915,20 @@ __global__ __launch_bounds__(256) void cl_col2im_kernel(const ClCol2imArgs a) {
         if (a.scatter) { const int q = o[d] + a.p[d]; k0[d] = q % a.s[d]; i0[d] = q / a.s[d]; kst[d] = a.s[d]; ist[d] = -1; }
         else { k0[d] = 0; i0[d] = o[d] * a.s[d] - a.p[d]; kst[d] = 1; ist[d] = 1; }
     }
-    const __bf16* zn = a.z + (int64_t)n * a.s_sp * a.zpitch;
+    const cl_h* zn = a.z + (int64_t)n * a.s_sp * a.zpitch;
     for (int kd = k0[0], id = i0[0]; kd < a.k[0]; kd += kst[0], id += ist[0]) {
         if ((unsigned)id >= (unsigned)a.sext[0]) continue;
         for (int kh = k0[1], ih = i0[1]; kh < a.k[1]; kh += kst[1], ih += ist[1]) {
             if ((unsigned)ih >= (unsigned)a.sext[1]) continue;
-            const __bf16* zr = zn + ((int64_t)id * a.s_hw + (int64_t)ih * a.s_w) * a.zpitch + ((kd * a.k[1] + kh) * a.k[2]) * a.OC;
+            const cl_h* zr = zn + ((int64_t)id * a.s_hw + (int64_t)ih * a.s_w) * a.zpitch + ((kd * a.k[1] + kh) * a.k[2]) * a.OC;
             for (int kw = k0[2], iw = i0[2]; kw < a.k[2]; kw += kst[2], iw += ist[2]) {
                 if ((unsigned)iw >= (unsigned)a.sext[2]) continue;
-                const __bf16* zp = zr + (int64_t)iw * a.zpitch + kw * a.OC;
+                const cl_h* zp = zr + (int64_t)iw * a.zpitch + kw * a.OC;
                 for (int e = 0; e < a.OC; ++e) acc[e] += (float)zp[e];
             }
         }
     }
-    __bf16* yp = a.y + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
+    cl_h* yp = a.y + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(256) void cl_col2im_kernel(const ClCol2imArgs a) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     u32x4 o4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; o4[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2)); }
+    for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; o4[q] = cl_pack2(f[0], f[1]); }
     *reinterpret_cast<u32x4*>(yp) = o4;
 }
 
@@ -943,7 +958,7 @@ __global__ __launch_bounds__(256) void cl_col2im_kernel(const ClCol2imArgs a) {
 // Roofline: HBM (source once + destination once).
 // --------------------------------------------------------------------------- //
 struct ClThin3Args {
-    const __bf16* x; __bf16* y; const __bf16* wp;
+    const cl_h* x; cl_h* y; const cl_h* wp;
     int32_t N, H, OC, act;
     int32_t pad0, bands;            // bands of 16 rows per image
     float slope; int32_t pad;
@@ -969,14 +984,14 @@ __global__ __launch_bounds__(256) void cl_thin3x3_kernel(const ClThin3Args a) {
 
     for (int i = tid; i < RING * ZROW; i += 256) zring[i] = 0.f;      // zero columns (and rows nobody has written yet)
 
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
     // weights: A fragments of all K steps in registers
-    bf16x8 wfrag[STEPS][2];
+    cl_h8 wfrag[STEPS][2];
 #pragma unroll
     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) wfrag[st][h] = *reinterpret_cast<const bf16x8*>(a.wp + ((st * 32 + l31) * 32 + (2 * h + lhi) * 8));
+        for (int h = 0; h < 2; ++h) wfrag[st][h] = *reinterpret_cast<const cl_h8*>(a.wp + ((st * 32 + l31) * 32 + (2 * h + lhi) * 8));
     // staging roles: granule gi = i * 64 + lane of the unit -> pixel gi / CPX, physical granule gi % CPX holding logical granule ^ swz(pixel)
     uint32_t voff[PPU];
 #pragma unroll
@@ -1019,8 +1034,8 @@ __global__ __launch_bounds__(256) void cl_thin3x3_kernel(const ClThin3Args a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int lg = st * 4 + 2 * h + lhi;
-                const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(xb + l31 * (CPX * 16) + ((lg ^ ((l31 >> SH) & MASK)) << 4));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[st][h], b8, acc, 0, 0, 0);
+                const cl_h8 b8 = *reinterpret_cast<const cl_h8*>(xb + l31 * (CPX * 16) + ((lg ^ ((l31 >> SH) & MASK)) << 4));
+                acc = CL_MFMA(wfrag[st][h], b8, acc, 0, 0, 0);
             }
         {
             const int zr = zr0 + 2 * t + wrow;
@@ -1057,7 +1072,7 @@ __global__ __launch_bounds__(256) void cl_thin3x3_kernel(const ClThin3Args a) {
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
                 u32x4 o4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; o4[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2)); }
+                for (int q = 0; q < 4; ++q) { const f32x2_ f = {v[2 * q], v[2 * q + 1]}; o4[q] = cl_pack2(f[0], f[1]); }
                 __builtin_amdgcn_raw_buffer_store_b128(o4, yrs, vo, 0, 0);
             }
         }
@@ -1075,7 +1090,7 @@ __global__ __launch_bounds__(256) void cl_thin3x3_kernel(const ClThin3Args a) {
 // owns its pixels).  No K loop, no workgroup barrier after the staging.  Roofline: HBM (destination once).
 // --------------------------------------------------------------------------- //
 struct ClWiden3Args {
-    const __bf16* x; __bf16* y; const __bf16* wp;      // wp: the thin packed format [3 steps][OCp][32], k = (tap & 3) * 8 + channel
+    const cl_h* x; cl_h* y; const cl_h* wp;      // wp: the thin packed format [3 steps][OCp][32], k = (tap & 3) * 8 + channel
     int32_t N, H, OCp, act;
     int32_t bands, pad0;
     float slope; int32_t pad1;
@@ -1094,7 +1109,7 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
     const int img = (int)((slot / (unsigned)a.bands) * 8u + xcd), band = (int)(slot % (unsigned)a.bands);
     if (img >= a.N) return;
     const int b0 = band * 16;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
     if (tid < 2 * ROWS) *reinterpret_cast<u32x4*>(smem + (tid >> 1) * RP + (tid & 1) * (W + 1) * 16) = u32x4{0u, 0u, 0u, 0u};      // the zero pixels left and right of each row
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1106,13 +1121,13 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
     }
 #endif
     // weights: A fragments of the three K steps (12 tap slots, 9 used; the packed buffer holds zeros in the others) for every 32-channel block
-    bf16x8 wfrag[OCB][3][2];
+    cl_h8 wfrag[OCB][3][2];
 #pragma unroll
     for (int ob = 0; ob < OCB; ++ob)
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) wfrag[ob][st][h] = *reinterpret_cast<const bf16x8*>(a.wp + (((int64_t)st * a.OCp + ob * 32 + l31) * 32 + (2 * h + lhi) * 8));
+            for (int h = 0; h < 2; ++h) wfrag[ob][st][h] = *reinterpret_cast<const cl_h8*>(a.wp + (((int64_t)st * a.OCp + ob * 32 + l31) * 32 + (2 * h + lhi) * 8));
     // B fragment of (step, half): the source pixel of tap = 4 step + 2 half + lhi at this lane's destination pixel; tap slots past the ninth read the zero pixel
     uint32_t boff[3][2];
 #pragma unroll
@@ -1130,11 +1145,11 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
     for (int u = wave; u < 32; u += 4) {
         const int r = u >> 1, half = u & 1;
         const uint32_t ubase = (uint32_t)((r * (W + 2) + half * 32) * 16);
-        bf16x8 b8[3][2];
+        cl_h8 b8[3][2];
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) b8[st][h] = *reinterpret_cast<const bf16x8*>(smem + (boff[st][h] == 0xffffffffu ? 0u : ubase + boff[st][h]));
+            for (int h = 0; h < 2; ++h) b8[st][h] = *reinterpret_cast<const cl_h8*>(smem + (boff[st][h] == 0xffffffffu ? 0u : ubase + boff[st][h]));
 #pragma unroll
         for (int ob = 0; ob < OCB; ++ob) {
             f32x16 acc;
@@ -1143,7 +1158,7 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
 #pragma unroll
             for (int st = 0; st < 3; ++st)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[ob][st][h], b8[st][h], acc, 0, 0, 0);
+                for (int h = 0; h < 2; ++h) acc = CL_MFMA(wfrag[ob][st][h], b8[st][h], acc, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4];
@@ -1152,8 +1167,8 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
                 typedef float f32x2_ __attribute__((ext_vector_type(2)));
                 const f32x2_ p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
                 u32x2 o;
-                o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p0, bf16x2));
-                o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(p1, bf16x2));
+                o[0] = cl_pack2(p0[0], p0[1]);
+                o[1] = cl_pack2(p1[0], p1[1]);
                 *reinterpret_cast<u32x2*>(tw + l31 * EP + (ob * 32 + 8 * q + 4 * lhi) * 2) = o;
             }
         }
@@ -1312,6 +1327,9 @@ static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_d
     return DCV_OK;
 }
 
+#ifdef DCV_CL_FP16
+}  // inline namespace clf16
+#endif
 }  // namespace dcv
 
 using namespace dcv;
@@ -1361,7 +1379,7 @@ int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
         ta.OCgp = (ta.OCg + tg.bn - 1) / tg.bn * tg.bn;
         ta.nsteps = cl_cp(pl.RC) / 32;
         ta.ws_o = pl.ws_o; ta.ws_r = pl.ws_r;
-        ta.wp = static_cast<__bf16*>(packed);
+        ta.wp = static_cast<cl_h*>(packed);
         const int64_t tot = (int64_t)ta.nsteps * ta.OCgp * 32;
         if ((size_t)tot * 2 > bytes) return fail(DCV_EWORKSPACE, "cl_pack_weights: buffer too small");
         hipLaunchKernelGGL(cl_pack_thin_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, ta);
@@ -1381,7 +1399,7 @@ int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
         const size_t b = cl_class_pack_bytes(c, pl.RC, pl.OC);
         if (T == 0) continue;
         if (off + b > bytes) return fail(DCV_EWORKSPACE, "cl_pack_weights: buffer too small");
-        pa.wp[n] = reinterpret_cast<__bf16*>(static_cast<char*>(packed) + off);
+        pa.wp[n] = reinterpret_cast<cl_h*>(static_cast<char*>(packed) + off);
         pa.T[n] = T;
         pa.nsteps[n] = cl_thin(pl.RC) ? (T + 3) / 4 : T * (cl_cp(pl.RC) / 32);
         for (int t = 0; t < T; ++t) {
@@ -1423,7 +1441,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
             if (xb3 < (1ll << 31) && yb3 < (1ll << 31)) {
                 ClThin3Args t;
                 memset(&t, 0, sizeof(t));
-                t.x = static_cast<const __bf16*>(src_p); t.y = static_cast<__bf16*>(dst_p); t.wp = static_cast<const __bf16*>(packed);
+                t.x = static_cast<const cl_h*>(src_p); t.y = static_cast<cl_h*>(dst_p); t.wp = static_cast<const cl_h*>(packed);
                 t.N = src.n; t.H = src.h; t.OC = pl.OC; t.act = act; t.bands = src.h / 16; t.slope = slope;
                 t.x_sn = src.sn; t.y_sn = dst.sn; t.x_sh = (int32_t)src.sh; t.x_sw = (int32_t)src.sw; t.y_sh = (int32_t)dst.sh; t.y_sw = (int32_t)dst.sw;
                 t.x_bytes = (uint32_t)xb3; t.y_bytes = (uint32_t)yb3;
@@ -1431,7 +1449,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
                 if (C3 == 128) hipLaunchKernelGGL((cl_thin3x3_kernel<16>), dim3(nwg), dim3(256), 0, st, t);
                 else if (C3 == 64) hipLaunchKernelGGL((cl_thin3x3_kernel<8>), dim3(nwg), dim3(256), 0, st, t);
                 else hipLaunchKernelGGL((cl_thin3x3_kernel<4>), dim3(nwg), dim3(256), 0, st, t);
-                snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_thin3x3_kernel<%d> (fused GEMM + tap gather, thin destination, bf16 channels-last)", C3 / 8);
+                snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_thin3x3_kernel<%d> (fused GEMM + tap gather, thin destination, " CL_HALF_NAME " channels-last)", C3 / 8);
                 DCV_LAUNCH_CHECK();
                 return DCV_OK;
             }
@@ -1443,7 +1461,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     ClGatherPack pk;
     memset(&pk, 0, sizeof(pk));
     ClGatherArgs& a = pk.c[0];
-    a.x = static_cast<const __bf16*>(src_p); a.y = static_cast<__bf16*>(ws); a.wp = static_cast<const __bf16*>(packed);
+    a.x = static_cast<const cl_h*>(src_p); a.y = static_cast<cl_h*>(ws); a.wp = static_cast<const cl_h*>(packed);
     a.M = (int)Msrc; a.OCp = OCgp; a.T = 1; a.cblk = Cp / 32; a.nsteps = Cp / 32; a.y_c = pad8(OCg); a.x_cmax = 2 * pad8(pl.RC);      // Z owns its pixels (pitch zp >= pad8): whole 8-column groups, zeros past OCg
     a.div_sp = make_fastdiv((uint32_t)(src.d * src.h * src.w)); a.div_hw = make_fastdiv((uint32_t)(src.h * src.w)); a.div_w = make_fastdiv((uint32_t)src.w);
     ClDim one;
@@ -1462,7 +1480,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     // (2) gather the taps of every destination pixel
     ClCol2imArgs c;
     memset(&c, 0, sizeof(c));
-    c.z = static_cast<const __bf16*>(ws); c.y = static_cast<__bf16*>(dst_p);
+    c.z = static_cast<const cl_h*>(ws); c.y = static_cast<cl_h*>(dst_p);
     c.OC = pl.OC; c.zpitch = zp; c.T = T;
     const bool direct = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
     c.scatter = direct ? 0 : 1;
@@ -1475,7 +1493,7 @@ static int cl_conv_thin_out(int which, const dcv_conv_geom* g, const ClPlan& pl,
     c.total = (int64_t)dst.n * dst.d * dst.h * dst.w;
     if (c.total >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: too many destination pixels");
     hipLaunchKernelGGL(cl_col2im_kernel, dim3((unsigned)((c.total + 255) / 256)), dim3(256), 0, st, c);
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile> as a 1x1 GEMM over the source + cl_col2im_kernel (thin destination, bf16 channels-last)", tc.bn, tc.bm);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile> as a 1x1 GEMM over the source + cl_col2im_kernel (thin destination, " CL_HALF_NAME " channels-last)", tc.bn, tc.bm);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -1514,7 +1532,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
             cl_extent_bytes(src, 8) < (1ll << 31) && cl_extent_bytes(dst, pl.OC) < (1ll << 31)) {
             ClWiden3Args t;
             memset(&t, 0, sizeof(t));
-            t.x = static_cast<const __bf16*>(src_p); t.y = static_cast<__bf16*>(dst_p); t.wp = static_cast<const __bf16*>(packed);
+            t.x = static_cast<const cl_h*>(src_p); t.y = static_cast<cl_h*>(dst_p); t.wp = static_cast<const cl_h*>(packed);
             t.N = src.n; t.H = src.h; t.OCp = (pl.OC + cl_pick_tile(pl.OC).bn - 1) / cl_pick_tile(pl.OC).bn * cl_pick_tile(pl.OC).bn; t.act = act; t.bands = src.h / 16; t.slope = slope;
             t.x_sn = src.sn; t.y_sn = dst.sn; t.x_sh = (int32_t)src.sh; t.x_sw = (int32_t)src.sw; t.y_sh = (int32_t)dst.sh; t.y_sw = (int32_t)dst.sw;
             t.x_bytes = (uint32_t)cl_extent_bytes(src, 8); t.y_bytes = (uint32_t)cl_extent_bytes(dst, pl.OC);
@@ -1522,7 +1540,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
             hipStream_t st3 = static_cast<hipStream_t>(stream);
             if (pl.OC == 128) hipLaunchKernelGGL((cl_widen3x3_kernel<4>), dim3(nwg), dim3(256), 0, st3, t);
             else hipLaunchKernelGGL((cl_widen3x3_kernel<2>), dim3(nwg), dim3(256), 0, st3, t);
-            snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_widen3x3_kernel<%d> (fused, thin source, bf16 channels-last)", pl.OC / 32);
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_widen3x3_kernel<%d> (fused, thin source, " CL_HALF_NAME " channels-last)", pl.OC / 32);
             DCV_LAUNCH_CHECK();
             return DCV_OK;
         }
@@ -1546,9 +1564,9 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
         }
         if (T > 64) return fail(DCV_EUNSUPPORTED, "cl conv: more than 64 taps");
         ClGatherArgs& a = pk.c[n];
-        a.x = static_cast<const __bf16*>(src_p);
-        a.y = static_cast<__bf16*>(dst_p);
-        a.wp = reinterpret_cast<const __bf16*>(static_cast<const char*>(packed) + off);
+        a.x = static_cast<const cl_h*>(src_p);
+        a.y = static_cast<cl_h*>(dst_p);
+        a.wp = reinterpret_cast<const cl_h*>(static_cast<const char*>(packed) + off);
         off += b;
         const int64_t M64 = (int64_t)dst.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2];
         if (M64 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "cl conv: too many positions");
@@ -1571,7 +1589,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
         a.coalesce = (ocs % 8 == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && !no_coalesce) ? 1 : 0;
         if (gate) {
             if (!a.coalesce) return fail(DCV_EUNSUPPORTED, "cl conv: the gated epilogue needs the row-order store form");
-            a.gate = static_cast<const __bf16*>(gate); a.gate_slope = gate_slope;
+            a.gate = static_cast<const cl_h*>(gate); a.gate_slope = gate_slope;
         }
         a.x_bytes = (uint32_t)xb; a.y_bytes = (uint32_t)yb;
         for (int t = 0; t < T; ++t) {
@@ -1600,7 +1618,7 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     pk.ncls = n; pk.tiles_oc = OCp / tc.bn; pk.tiles_m = (int)maxtm;
     const dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
     cl_launch_tile(tc, pk, thin, grid, st);
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile%s> (%d class%s, bf16 channels-last)", tc.bn, tc.bm, thin ? ", thin" : "", n, n == 1 ? "" : "es");
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile%s> (%d class%s, " CL_HALF_NAME " channels-last)", tc.bn, tc.bm, thin ? ", thin" : "", n, n == 1 ? "" : "es");
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -1665,8 +1683,8 @@ static int cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const 
     if (rc != DCV_OK) return rc;
     const dcv_dims5& D = g->transposed ? *xd : *dyd;
     const dcv_dims5& G = g->transposed ? *dyd : *xd;
-    const __bf16* dp = static_cast<const __bf16*>(g->transposed ? x : dy);
-    const __bf16* gp = static_cast<const __bf16*>(g->transposed ? dy : x);
+    const cl_h* dp = static_cast<const cl_h*>(g->transposed ? x : dy);
+    const cl_h* gp = static_cast<const cl_h*>(g->transposed ? dy : x);
     if ((rc = cl_check_tensor(D, "cl wgrad dense operand")) != DCV_OK || (rc = cl_check_tensor(G, "cl wgrad gathered operand")) != DCV_OK) return rc;
     int64_t dpitch = 0;
     if (!cl_pixel_linear(D, &dpitch)) return fail(DCV_EUNSUPPORTED, "cl wgrad: the dense operand must be pixel-linear (a whole tensor or a channel slice of one)");
@@ -1762,7 +1780,7 @@ static int cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const 
         }
         DCV_LAUNCH_CHECK();
     }
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, bf16 channels-last)", p.tiles, p.S);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, " CL_HALF_NAME " channels-last)", p.tiles, p.S);
     return DCV_OK;
 }
 int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,

@@ -63,6 +63,36 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }  // namespace dcv
 
 #ifdef __HIPCC__
+// Element type of the 16-bit channels-last path (conv_cl16.hip, cl_elementwise.hip): bf16 by default; -DDCV_CL_FP16 compiles the same two translation units a second
+// time for fp16 — same MFMA rate and fragment path (v_mfma_f32_32x32x16_f16), 10 mantissa bits instead of 7, exponent range 6.5e4 instead of fp32's — with the entry
+// points renamed dcv_cl_* -> dcv_clf16_* (BASELINE configs[4] names fp16 MFMA; built for the discriminators' stress shape).
+namespace dcv {
+#ifdef DCV_CL_FP16
+typedef _Float16 cl_h;
+#define CL_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define CL_HALF_NAME "fp16"
+#else
+typedef __bf16 cl_h;
+#define CL_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define CL_HALF_NAME "bf16"
+#endif
+typedef cl_h cl_h8 __attribute__((ext_vector_type(8)));
+typedef cl_h cl_h2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two 16-bit values (round to nearest even), and back
+__device__ __forceinline__ uint32_t cl_pack2(float a, float b) {
+    typedef float f32x2c __attribute__((ext_vector_type(2)));
+    const f32x2c t = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(t, cl_h2));
+}
+#ifdef DCV_CL_FP16
+__device__ __forceinline__ float cl_lo(uint32_t w) { return (float)__builtin_bit_cast(cl_h2, w)[0]; }
+__device__ __forceinline__ float cl_hi(uint32_t w) { return (float)__builtin_bit_cast(cl_h2, w)[1]; }
+#else
+__device__ __forceinline__ float cl_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float cl_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+#endif
+__device__ __forceinline__ float cl_round(float v) { return (float)(cl_h)v; }      // the value as it will be stored
+}  // namespace dcv
 namespace dcv {
 // n / d for the FastDiv above (d == 1 handled by mul == 0 convention)
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv f) {

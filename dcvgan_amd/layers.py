@@ -25,6 +25,9 @@ _FUSE_BN_STATS = os.environ.get("DCV_NO_BN_FUSION") is None
 # its output, in execution order — the pattern the backward kernels differentiate with (tests/test_fullwidth_gpu.py
 # replays it in an fp64 evaluation of the same graph on the host).  None in production: nothing is recorded.
 KINK_TAP = None
+# Diagnostic of the 16-bit paths (bench.py's stress leg, tests/test_fp16_gpu.py): when a list is installed here, every convolution output that feeds a BatchNorm
+# appends its largest magnitude (a 0-d device tensor) — the un-normalised sums that decide whether fp16's 65504 is enough.  None in production.
+PREBN_TAP = None
 
 
 def _tap(y, fused):
@@ -89,6 +92,8 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             x = ops_cl.conv(x, layer.weight, geom_of(layer), *(fused or (ops.ACT_NONE, 0.0)), out=out if last else None, grad_slot=grad_slot if i == 0 else None, bn_stats=box,
                             act_slot=act_slot if (last and fused is not None) else None)
             pending = box[0] if box else None
+            if PREBN_TAP is not None and fused is None and isinstance(nxt, _BNS):
+                PREBN_TAP.append(x.detach().float().abs().max())
             i += 2 if fused is not None else 1
         elif isinstance(layer, _CONVS):
             fused = _act_of(nxt) if nxt is not None else None

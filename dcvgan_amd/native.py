@@ -112,6 +112,25 @@ _SIGS = {
     "dcv_cl_bn_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_size_t, _P]),
     "dcv_adam_step_multi": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, _P]),
     "dcv_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, _P]),
+    # the fp16 build of the channels-last path (same signatures; ABI 3)
+    "dcv_clf16_packed_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
+    "dcv_clf16_conv_workspace_bytes": (C.c_size_t, [_G, _D, _D, C.c_int]),
+    "dcv_clf16_pack_weights": (C.c_int, [_G, _D, _D, C.c_int, _P, _P, C.c_size_t, _P]),
+    "dcv_clf16_conv_forward": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_clf16_conv_stats_bytes": (C.c_size_t, [_G, _D, _D]),
+    "dcv_clf16_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, C.c_size_t, _P]),
+    "dcv_clf16_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_clf16_conv_backward_data_gated": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _D, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_clf16_wgrad_workspace_bytes": (C.c_size_t, [_G, _D, _D]),
+    "dcv_clf16_conv_backward_weight": (C.c_int, [_G, _P, _D, _P, _D, _P, _P, C.c_size_t, _P]),
+    "dcv_clf16_conv_backward_weight_acc": (C.c_int, [_G, _P, _D, _P, _D, _P, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_clf16_from_f32": (C.c_int, [_P, _D, _P, _D, _P]),
+    "dcv_clf16_to_f32": (C.c_int, [_P, _D, _P, _D, C.c_int, _P]),
+    "dcv_clf16_elementwise": (C.c_int, [C.c_int, _P, _D, _P, _D, _P, _D, C.c_float, C.c_float, C.c_uint64, C.c_uint64, _P]),
+    "dcv_clf16_bn_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "dcv_clf16_bn_act_forward": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_size_t, _P]),
+    "dcv_clf16_bn_act_forward_stats": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int, C.c_float, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "dcv_clf16_bn_act_backward": (C.c_int, [_P, _D, _P, _D, _P, _D, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, _P, _P, _P, C.c_size_t, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -493,7 +493,7 @@ class _NoiseAdd(Function):
 
 def noise_add(x, sigma: float, sample=None, seed: int = 0, offset: int = 0):
     """x + sigma * N(0,1): device Philox draw, or an injected `sample` tensor."""
-    if x.dtype == torch.bfloat16:       # bf16 channels-last data path
+    if x.dtype in (torch.bfloat16, torch.float16):       # 16-bit channels-last data path
         from . import ops_cl
         return ops_cl.noise_add(x, sigma, sample, seed, offset)
     return _NoiseAdd.apply(x, float(sigma), sample, int(seed), int(offset))

@@ -24,11 +24,23 @@ _FUSE_BN_STATS = os.environ.get("DCV_NO_BN_FUSION") is None
 
 BF16 = torch.bfloat16
 _ENABLED = [False]
+_HALF = [torch.bfloat16]          # element type of the path: bf16 (default) or fp16 (the library's dcv_clf16_* build of the same kernels; BASELINE configs[4] names fp16 MFMA)
 
 
-def enable(on: bool = True) -> None:
-    """Process-wide switch: models built on dcvgan_amd.layers run their convolution / BatchNorm chains on the CL16 path."""
+def enable(on: bool = True, half: str = "bf16") -> None:
+    """Process-wide switch: models built on dcvgan_amd.layers run their convolution / BatchNorm chains on the CL16 path.  `half`: "bf16" or "fp16" — one element type
+    at a time (a tensor of the other one is refused by `_req`)."""
     _ENABLED[0] = bool(on)
+    _HALF[0] = {"bf16": torch.bfloat16, "fp16": torch.float16}[half]
+
+
+def half_dtype():
+    return _HALF[0]
+
+
+def _fn(name: str):
+    """The library entry point `dcv_cl_<name>` (bf16) or `dcv_clf16_<name>` (fp16) for the element type in use."""
+    return getattr(lib(), ("dcv_clf16_" if _HALF[0] is torch.float16 else "dcv_cl_") + name)
 
 
 def active() -> bool:
@@ -48,18 +60,18 @@ def cl_empty(shape, device, pitch: Optional[int] = None, zero: bool = False) -> 
     n, c, sp = shape[0], shape[1], tuple(shape[2:])
     p = pitch if pitch is not None else pitch_of(c)
     make = torch.zeros if zero else torch.empty
-    store = make((n,) + sp + (p,), dtype=BF16, device=device)
+    store = make((n,) + sp + (p,), dtype=_HALF[0], device=device)
     perm = (0, len(sp) + 1) + tuple(range(1, len(sp) + 1))
     return store.permute(*perm)[:, :c]
 
 
 def is_cl(t: torch.Tensor) -> bool:
-    return t.dtype == BF16
+    return t.dtype == torch.bfloat16 or t.dtype == torch.float16
 
 
 def _req(t: torch.Tensor, what: str):
-    if not t.is_cuda or t.dtype != BF16:
-        raise N.NativeError(f"{what}: expected a bf16 HIP tensor, got {t.dtype} on {t.device}")
+    if not t.is_cuda or t.dtype != _HALF[0]:
+        raise N.NativeError(f"{what}: expected a {_HALF[0]} HIP tensor (the element type ops_cl.enable selected), got {t.dtype} on {t.device}")
     if t.dim() > 1 and t.shape[1] > 1 and t.stride(1) != 1:
         raise N.NativeError(f"{what}: expected channels-last memory (channel stride 1), got strides {tuple(t.stride())}")
     if t.device.index != torch.cuda.current_device():
@@ -68,7 +80,7 @@ def _req(t: torch.Tensor, what: str):
 
 def as_cl(t: torch.Tensor) -> torch.Tensor:
     """A gradient handed over by autograd: already channels-last in practice (sums of CL tensors keep their strides); anything else is re-laid."""
-    if t.dtype == BF16 and (t.shape[1] == 1 or t.stride(1) == 1) and all(s != 0 or n == 1 for s, n in zip(t.stride(), t.shape)):
+    if t.dtype == _HALF[0] and (t.shape[1] == 1 or t.stride(1) == 1) and all(s != 0 or n == 1 for s, n in zip(t.stride(), t.shape)):
         st = t.stride()
         if t.dim() < 3 or st[-1] % 8 == 0:
             return t
@@ -86,7 +98,7 @@ class _FromF32(Function):
         N._require(x, "from_f32 input")
         y = cl_empty(x.shape, x.device) if out is None else out.t.detach()
         xd, yd = dims5(x), dims5(y)
-        check(lib().dcv_cl_from_f32(ptr(x), C.byref(xd), ptr(y), C.byref(yd), stream_ptr()), "dcv_cl_from_f32")
+        check(_fn("from_f32")(ptr(x), C.byref(xd), ptr(y), C.byref(yd), stream_ptr()), "dcv_cl_from_f32")
         return y
 
     @staticmethod
@@ -94,7 +106,7 @@ class _FromF32(Function):
         dy = as_cl(dy)
         dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
         dyd, dxd = dims5(dy), dims5(dx)
-        check(lib().dcv_cl_to_f32(ptr(dy), C.byref(dyd), ptr(dx), C.byref(dxd), 0, stream_ptr()), "dcv_cl_to_f32")
+        check(_fn("to_f32")(ptr(dy), C.byref(dyd), ptr(dx), C.byref(dxd), 0, stream_ptr()), "dcv_cl_to_f32")
         return dx, None
 
 
@@ -109,7 +121,7 @@ class _ToF32(Function):
         _req(x, "to_f32 input")
         y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         xd, yd = dims5(x), dims5(y)
-        check(lib().dcv_cl_to_f32(ptr(x), C.byref(xd), ptr(y), C.byref(yd), 0, stream_ptr()), "dcv_cl_to_f32")
+        check(_fn("to_f32")(ptr(x), C.byref(xd), ptr(y), C.byref(yd), 0, stream_ptr()), "dcv_cl_to_f32")
         return y
 
     @staticmethod
@@ -118,7 +130,7 @@ class _ToF32(Function):
             dy = dy.contiguous()
         dx = cl_empty(dy.shape, dy.device)
         dyd, dxd = dims5(dy), dims5(dx)
-        check(lib().dcv_cl_from_f32(ptr(dy), C.byref(dyd), ptr(dx), C.byref(dxd), stream_ptr()), "dcv_cl_from_f32")
+        check(_fn("from_f32")(ptr(dy), C.byref(dyd), ptr(dx), C.byref(dxd), stream_ptr()), "dcv_cl_from_f32")
         return dx
 
 
@@ -134,7 +146,7 @@ def _ew(kind, x, z, a=0.0, b=0.0, seed=0, offset=0, out=None):
     y = cl_empty(x.shape, x.device, pitch=None) if out is None else out
     xd, yd = dims5(x), dims5(y)
     zd = dims5(z) if z is not None else None
-    check(lib().dcv_cl_elementwise(kind, ptr(x), C.byref(xd), ptr(z), C.byref(zd) if z is not None else None, ptr(y), C.byref(yd), float(a), float(b),
+    check(_fn("elementwise")(kind, ptr(x), C.byref(xd), ptr(z), C.byref(zd) if z is not None else None, ptr(y), C.byref(yd), float(a), float(b),
                                    int(seed), int(offset), stream_ptr()), "dcv_cl_elementwise")
     return y
 
@@ -154,7 +166,7 @@ class _NoiseAddCl(Function):
 
 def noise_add(x, sigma: float, sample=None, seed: int = 0, offset: int = 0):
     """x + sigma N(0,1) on a CL16 tensor; `sample`: an injected fp32 draw (converted) instead of the device Philox stream."""
-    if sample is not None and sample.dtype != BF16:
+    if sample is not None and sample.dtype != _HALF[0]:
         with torch.no_grad():
             sample = from_f32(sample)
     return _NoiseAddCl.apply(x, float(sigma), sample, int(seed), int(offset))
@@ -188,17 +200,17 @@ def _packed(w: torch.Tensor, which: int, g: ConvGeom, xd, yd, key_dims):
     cache = getattr(w, "_dcv_clpack", None)
     if cache is None:
         cache = w._dcv_clpack = {}
-    key = (which, g.key(), key_dims)
+    key = (which, g.key(), key_dims, _HALF[0])
     e = cache.get(key)
     stamp = (w._version, w.data_ptr())
     L = lib()
     if e is None:
-        nb = L.dcv_cl_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), which)
+        nb = _fn("packed_bytes")(C.byref(g), C.byref(xd), C.byref(yd), which)
         if nb == 0:
             raise N.NativeError("dcv_cl_packed_bytes: " + L.dcv_last_error().decode())
         e = cache[key] = [None, torch.empty(nb, dtype=torch.uint8, device=w.device)]
     if e[0] != stamp:
-        check(L.dcv_cl_pack_weights(C.byref(g), C.byref(xd), C.byref(yd), which, ptr(w), ptr(e[1]), e[1].numel(), stream_ptr()), "dcv_cl_pack_weights")
+        check(_fn("pack_weights")(C.byref(g), C.byref(xd), C.byref(yd), which, ptr(w), ptr(e[1]), e[1].numel(), stream_ptr()), "dcv_cl_pack_weights")
         e[0] = stamp
     return e[1]
 
@@ -220,18 +232,18 @@ class _ConvCl(Function):
             raise N.NativeError(f"out= has shape {tuple(y.shape)}, expected {tuple(shape)}")
         xd, yd = dims5(x), dims5(y)
         pk = _packed(w, 0, g, xd, yd, tuple(x.shape))
-        wsp, wsn = _ws("clconv", lib().dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(yd), 0), x.device)
-        sbytes = lib().dcv_cl_conv_stats_bytes(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE and _FUSE_BN_STATS) else 0
+        wsp, wsn = _ws("clconv", _fn("conv_workspace_bytes")(C.byref(g), C.byref(xd), C.byref(yd), 0), x.device)
+        sbytes = _fn("conv_stats_bytes")(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE and _FUSE_BN_STATS) else 0
         if sbytes:
             # conv -> BatchNorm pair: the epilogue leaves per-tile {sum, sum^2} of the stored bf16 values, the BatchNorm op skips its statistics pass over y
             stat = torch.empty(sbytes // 4, dtype=torch.float32, device=x.device)
             nparts, pitch = C.c_int(0), C.c_int(0)
-            check(lib().dcv_cl_conv_forward_stats(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), ptr(stat), sbytes, C.byref(nparts), C.byref(pitch),
+            check(_fn("conv_forward_stats")(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), ptr(stat), sbytes, C.byref(nparts), C.byref(pitch),
                                                   wsp, wsn, stream_ptr()), "dcv_cl_conv_forward_stats")
             if nparts.value > 0:
                 bn_stats.append((stat, nparts.value, pitch.value))
         else:
-            check(lib().dcv_cl_conv_forward(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_cl_conv_forward")
+            check(_fn("conv_forward")(C.byref(g), ptr(x), C.byref(xd), ptr(pk), ptr(y), C.byref(yd), act, slope, wsp, wsn, stream_ptr()), "dcv_cl_conv_forward")
         ctx.g, ctx.act, ctx.slope = g, act, slope
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -254,37 +266,37 @@ class _ConvCl(Function):
             # slice in the GEMM epilogue and hand autograd nothing to sum (ops.GradSlot, as on the fp32 path)
             slot = ctx.grad_slot
             into = slot.take(x) if slot is not None else None
-            if into is not None and (into.dtype != BF16 or into.stride() != x.stride()):
+            if into is not None and (into.dtype != _HALF[0] or into.stride() != x.stride()):
                 slot.g, into = into, None
             dx = into if into is not None else cl_empty(x.shape, x.device)
             dxd = dims5(dx)
             pk = _packed(w, 1, g, dxd, dyd, tuple(x.shape))
-            wsp, wsn = _ws("clconv", L.dcv_cl_conv_workspace_bytes(C.byref(g), C.byref(dxd), C.byref(dyd), 1), x.device)
+            wsp, wsn = _ws("clconv", _fn("conv_workspace_bytes")(C.byref(g), C.byref(dxd), C.byref(dyd), 1), x.device)
             rc = N.DCV_EUNSUPPORTED
             from . import ops as _o2
             if into is not None and slot.act is not None and _o2._GATED_DGRAD and tuple(x.stride()) == tuple(into.stride()):
                 # ... and the derivative of the activation that produced x, read off x, in the same epilogue (Inconv -> DownBlock 0)
                 xgd = dims5(x)
-                rc = L.dcv_cl_conv_backward_data_gated(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 1, ptr(x), C.byref(xgd),
+                rc = _fn("conv_backward_data_gated")(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), 1, ptr(x), C.byref(xgd),
                                                        slot.act[0], slot.act[1], wsp, wsn, stream_ptr())
                 if rc == 0:
                     slot.act_applied = True
                 elif rc != N.DCV_EUNSUPPORTED:
                     check(rc, "dcv_cl_conv_backward_data_gated")
             if rc == N.DCV_EUNSUPPORTED:
-                check(L.dcv_cl_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), int(into is not None), wsp, wsn, stream_ptr()),
+                check(_fn("conv_backward_data")(C.byref(g), ptr(dy), C.byref(dyd), ptr(pk), ptr(dx), C.byref(dxd), int(into is not None), wsp, wsn, stream_ptr()),
                       "dcv_cl_conv_backward_data")
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:
-            need = L.dcv_cl_wgrad_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd))
+            need = _fn("wgrad_workspace_bytes")(C.byref(g), C.byref(xd), C.byref(dyd))
             if need == 0:
                 raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + L.dcv_last_error().decode())
             wsp, wsn = _ws("clconv", need, x.device)
             from . import ops as _o
             tgt = _o.grad_target(w) if _o._OWN_ACCUMULATION else None
             if tgt is not None:      # a later contribution to this parameter's gradient: added by the slab reduce (ops.grad_target), nothing for autograd to sum
-                check(L.dcv_cl_conv_backward_weight_acc(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
+                check(_fn("conv_backward_weight_acc")(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
                       "dcv_cl_conv_backward_weight_acc")
             else:
                 slot = getattr(w, "_dcv_grad_slot", None)       # data parallel: the parameter's slice of its bucket's flat buffer (optim.GradBucket), as on the fp32 path
@@ -293,7 +305,7 @@ class _ConvCl(Function):
                     dw = slot.detach()
                 else:
                     dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
-                check(L.dcv_cl_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
+                check(_fn("conv_backward_weight")(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
                 if _o._OWN_ACCUMULATION:
                     _o.note_first(w, dw)
         return dx, dw, None, None, None, None, None, None, None
@@ -318,14 +330,14 @@ class _BnActCl(Function):
         y = cl_empty(x.shape, x.device) if out is None else out.t.detach()
         stats = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         xd, yd = dims5(x), dims5(y)
-        wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
+        wsp, wsn = _ws("clbn", _fn("bn_workspace_bytes")(Cn), x.device)
         if partials is not None and training:
             stat, nparts, pitch = partials.v
-            check(L.dcv_cl_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+            check(_fn("bn_act_forward_stats")(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                 ptr(nbt), ptr(stats[0]), ptr(stats[1]), ptr(mask), momentum, eps, act, slope, ptr(stat), nparts, pitch,
                                                 wsp, wsn, stream_ptr()), "dcv_cl_bn_act_forward_stats")
         else:
-            check(L.dcv_cl_bn_act_forward(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+            check(_fn("bn_act_forward")(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                           ptr(nbt) if training else None, ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), momentum, eps, act, slope,
                                           wsp, wsn, stream_ptr()), "dcv_cl_bn_act_forward")
         ctx.cfg = (bool(training), act, slope)
@@ -342,8 +354,8 @@ class _BnActCl(Function):
         dx = cl_empty(x.shape, x.device)
         dgb = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         dyd, xd, dxd = dims5(dy), dims5(x), dims5(dx)
-        wsp, wsn = _ws("clbn", L.dcv_cl_bn_workspace_bytes(Cn), x.device)
-        check(L.dcv_cl_bn_act_backward(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]),
+        wsp, wsn = _ws("clbn", _fn("bn_workspace_bytes")(Cn), x.device)
+        check(_fn("bn_act_backward")(ptr(dy), C.byref(dyd), ptr(x), C.byref(xd), ptr(dx), C.byref(dxd), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]),
                                        ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()), "dcv_cl_bn_act_backward")
         from . import ops as _o
         if _o._OWN_ACCUMULATION:

@@ -320,6 +320,31 @@ int dcv_cl_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, 
                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const float* mask,
                            int training, int act, float slope, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
+
+/* ---- the same 16-bit channels-last path with fp16 as its element type (ABI 3) ------------ *
+ * BASELINE configs[4] names "fp16 MFMA" (config/isogd-flow.yml on 32 x 128 x 128 clips: the size-agnostic discriminators, discriminator.py:181-206,288-305).
+ * conv_cl16.hip / cl_elementwise.hip are compiled a second time with _Float16 as the element type and v_mfma_f32_32x32x16_f16: identical layout, kernels and
+ * semantics, 10 mantissa bits instead of 7, largest finite value 65504 (a pre-BatchNorm sum beyond it becomes inf: the stress leg of bench.py reports the
+ * largest magnitude it saw).  Same signatures as the dcv_cl_* entry points above; tensors are torch.float16 on the host side. */
+size_t dcv_clf16_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which );
+size_t dcv_clf16_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which);
+int dcv_clf16_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which, const float* w, void* packed, size_t bytes, void* stream);
+int dcv_clf16_conv_forward(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+size_t dcv_clf16_conv_stats_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
+int dcv_clf16_conv_forward_stats(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* packed, void* y, const dcv_dims5* yd, float* stat, size_t stat_bytes, int* nparts, int* pitch, void* ws, size_t ws_bytes, void* stream);
+int dcv_clf16_conv_backward_data(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int dcv_clf16_conv_backward_data_gated(const dcv_conv_geom* g, const void* dy, const dcv_dims5* dyd, const void* packed, void* dx, const dcv_dims5* dxd, int accumulate, const void* xg, const dcv_dims5* xgd, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+size_t dcv_clf16_wgrad_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y);
+int dcv_clf16_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw, void* ws, size_t ws_bytes, void* stream);
+int dcv_clf16_conv_backward_weight_acc(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw, int accumulate, void* ws, size_t ws_bytes, void* stream);
+int dcv_clf16_from_f32(const float* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, void* stream);
+int dcv_clf16_to_f32(const void* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, int accumulate, void* stream);
+int dcv_clf16_elementwise(int kind, const void* x, const dcv_dims5* xd, const void* z, const dcv_dims5* zd, void* y, const dcv_dims5* yd, float a, float b, uint64_t seed, uint64_t offset, void* stream);
+size_t dcv_clf16_bn_workspace_bytes(int channels);
+int dcv_clf16_bn_act_forward(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, const float* mask, int training, float momentum, float eps, int act, float slope, void* ws, size_t ws_bytes, void* stream);
+int dcv_clf16_bn_act_forward_stats(const void* x, const dcv_dims5* xd, void* y, const dcv_dims5* yd, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, const float* mask, float momentum, float eps, int act, float slope, const float* stat, int nparts, int pitch, void* ws, size_t ws_bytes, void* stream);
+int dcv_clf16_bn_act_backward(const void* dy, const dcv_dims5* dyd, const void* x, const dcv_dims5* xd, void* dx, const dcv_dims5* dxd, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const float* mask, int training, int act, float slope, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -432,6 +432,7 @@ def test_gated_skip_gradient_cl16():
             ops._GATED_DGRAD = old
             ops_cl.enable(False)
 
+    run(True)                                          # (the first pass also builds the weight gradients' position tables, kept per geometry)
     ga, la = run(True)
     gb, lb = run(False)
     assert la == lb - 1, (la, lb)                      # exactly the derivative pass is gone

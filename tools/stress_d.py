@@ -1,6 +1,7 @@
 """32 x 128 x 128 discriminator stress shape (SURVEY §8(d) "D5"): vdis + gdis forward/backward on flow clips
-(Cg = 2), HIP-event timed.  Usage: python tools/stress_d.py [B] [fp32|bf16|f32x6|bf16cl]
-(bf16cl = the bf16 channels-last data path: BASELINE configs[4] names a 16-bit MFMA run of this shape)"""
+(Cg = 2), HIP-event timed.  Usage: python tools/stress_d.py [B] [fp32|bf16|f32x6|bf16cl|fp16cl]
+(bf16cl / fp16cl = the 16-bit channels-last data path with bf16 / fp16 elements: BASELINE configs[4] names an fp16 MFMA run of this shape;
+ they also print the largest pre-BatchNorm magnitude — fp16's largest finite value is 65504 — and how many parameter-gradient elements came out zero)"""
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -10,9 +11,10 @@ native.lib()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 MODE = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-if MODE == "bf16cl":
-    from dcvgan_amd import ops_cl
-    ops_cl.enable(True)
+CL = MODE in ("bf16cl", "fp16cl")
+if CL:
+    from dcvgan_amd import layers, ops_cl
+    ops_cl.enable(True, half=MODE[:4])
 else:
     native.set_precision(MODE)
 torch.manual_seed(0)
@@ -30,8 +32,15 @@ def step():
     return yv, yg
 
 
+if CL:
+    layers.PREBN_TAP = []
 yv, yg = step()
 torch.cuda.synchronize()
+if CL:
+    peak = max(float(t) for t in layers.PREBN_TAP); layers.PREBN_TAP = None
+    gs = [p.grad for m in (vdis, gdis) for p in m.parameters() if p.grad is not None]
+    zero = sum(int((g == 0).sum()) for g in gs); tot = sum(g.numel() for g in gs)
+    print(f"{MODE} B={B}: largest pre-BatchNorm magnitude {peak:.2f}; parameter-gradient elements exactly zero {zero} of {tot} ({zero / tot:.2%}); all finite {all(bool(torch.isfinite(g).all()) for g in gs)}")
 print("shapes", tuple(yv.shape), tuple(yg.shape), "finite", bool(torch.isfinite(yv).all() and torch.isfinite(yg).all()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
