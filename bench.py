@@ -240,6 +240,50 @@ def committed_step_traffic(config, batch, cl=False):
     return None, None
 
 
+def stress_leg(dev, half, B=100, steps=5):
+    """BASELINE configs[4]'s discriminator shape: vdis + gdis (config/isogd-flow.yml widths: ndf 64 / 32, Noise sigma 0.2 on vdis) forward + backward on 32 x 128 x 128 flow
+    clips, on the 16-bit channels-last data path with `half` = "bf16" or "fp16" elements (3 x (55.1 + 13.6) GFLOP per clip).  Besides the rate: the largest
+    pre-BatchNorm magnitude (fp16's largest finite value is 65504) and how many parameter-gradient elements came out exactly zero (fp16's smallest normal number is 6.1e-5;
+    the cotangent of a mean over the logits starts near 1e-6 at this batch)."""
+    from dcvgan_amd import discriminator as D, layers, ops_cl
+    ops_cl.enable(True, half=half)
+    try:
+        torch.manual_seed(0)
+        vdis = D.VideoDiscriminator(2, 3, True, 0.2, 64).to(dev)
+        gdis = D.GradientDiscriminator(2, 3, False, 0.2, 32).to(dev)
+        xc = (torch.rand(B, 3, 32, 128, 128, device=dev) * 2 - 1).requires_grad_(True)
+        xg = (torch.rand(B, 2, 32, 128, 128, device=dev) - 0.5).requires_grad_(True)
+
+        def step():
+            for m in (vdis, gdis):
+                m.zero_grad()
+            yv, yg = vdis(xg, xc), gdis(xg, xc)
+            (yv.mean() + yg.mean()).backward()
+            return yv, yg
+        layers.PREBN_TAP = []
+        yv, yg = step()
+        torch.cuda.synchronize()
+        peak = max(float(t) for t in layers.PREBN_TAP)
+        layers.PREBN_TAP = None
+        gs = [p.grad for m in (vdis, gdis) for p in m.parameters() if p.grad is not None]
+        zero, tot = sum(int((g == 0).sum()) for g in gs), sum(g.numel() for g in gs)
+        finite = bool(torch.isfinite(yv).all() and torch.isfinite(yg).all() and all(bool(torch.isfinite(g).all()) for g in gs))
+        step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record(); e1.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        gf = 3 * (55.1 + 13.6) * B
+        return {"value": B / ms * 1e3, "unit": "clips/s (vdis + gdis forward + backward)", "ms_per_step": ms, "per_gpu_batch": B, "tflops": gf / ms, "frac_of_its_mfma_peak": gf / ms / PEAK_BF16_MFMA_TFLOPS,
+                "all_finite": finite, "largest_pre_batchnorm_magnitude": peak, "fp16_largest_finite": 65504.0,
+                "parameter_gradient_elements_exactly_zero": zero, "parameter_gradient_elements": tot, "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 1e9}
+    finally:
+        layers.PREBN_TAP = None
+        ops_cl.enable(False, half="bf16")
+
+
 def host_threads():
     """CPUs this process may really use: affinity mask, capped by a cgroup CPU quota if one is set."""
     n = len(os.sched_getaffinity(0))
@@ -487,8 +531,17 @@ def main():
                 ops_cl.enable(False)
                 native.set_precision("fp32")
             torch.cuda.empty_cache()
+        # BASELINE configs[4]: the 32 x 128 x 128 discriminator shape in fp16 (as worded) and in bf16, one after the other in this call
+        for half in ("bf16", "fp16"):
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(dev)
+            try:
+                secondary[f"{half}cl:stress_d_32x128x128"] = stress_leg(dev, half)
+            except Exception as e:
+                secondary[f"{half}cl:stress_d_32x128x128"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
         secondary["note"] = ("NOT the headline: bf16cl = bf16 channels-last data path (activations / gradients bf16 in HBM, fp32 masters, statistics, accumulation, optimiser; "
-                             "tolerance tests tests/test_cl16_gpu.py); f32x6 = fp32 emulated on the bf16 matrix pipe in the forward / data-gradient GEMMs (3-way bf16 split, six products, sign-alternating accumulation; the fp32 parity suites pass with it as the process default; experimental, not the default); DESIGN §8")
+                             "tolerance tests tests/test_cl16_gpu.py); stress_d_32x128x128 = BASELINE configs[4]'s discriminator shape (vdis + gdis forward + backward on 32 x 128 x 128 flow clips, B = 100) on the same path with bf16 and with fp16 elements (dcv_clf16_*; tests/test_fp16_gpu.py); f32x6 = fp32 emulated on the bf16 matrix pipe in the forward / data-gradient GEMMs (3-way bf16 split, six products, sign-alternating accumulation; the fp32 parity suites pass with it as the process default; experimental, not the default); DESIGN §8")
 
     if rank == 0:
         per_step = dt / a.steps
