@@ -1184,6 +1184,84 @@ __global__ __launch_bounds__(256) void cl_widen3x3_kernel(const ClWiden3Args a) 
     }
 }
 
+
+// --------------------------------------------------------------------------- //
+// Thin source, fused, 3-D (round 5): the video / gradient discriminators' stems — Conv3d(<= 8 -> 32, 4x4x4, stride (1, 2, 2), padding (0, 1, 1)) + LeakyReLU on
+// 64 x 64 frames (discriminator.py:181-186,288-291).  The tiled thin gather reads 64 taps x 16 bytes per output position out of L2 (1.4 GB per launch for a 105 MB
+// input: 0.18 ms, nine launches per iteration).  Here a workgroup owns 4 output rows of one (sample, output depth): the 10 x 4 input rows it needs (a 1 KB LDS-DMA
+// each, a zero pixel left and right) are staged once, a wave owns one output row of 32 pixels, an MFMA operand fragment is ONE staged pixel at a compile-time
+// offset per (tap, half) — no per-lane address arithmetic in the K loop — and the 32 x 32 result leaves through a wave-private LDS transpose as 16-byte granules.
+// The 13 output depths of a row band run back to back on one XCD (they share three of their four input planes).  Roofline: HBM (input + output once).
+// --------------------------------------------------------------------------- //
+struct ClStem3Args {
+    const cl_h* x; cl_h* y; const cl_h* wp;      // wp: thin packed format [16 steps][32][32], step = kd * 4 + kh, k = kw * 8 + channel
+    int32_t N, OD, act, pad0;
+    float slope; int32_t pad1;
+    int64_t x_sn, y_sn;
+    int32_t x_sd, x_sh, x_sw, y_sd, y_sh, y_sw;
+    uint32_t x_bytes, y_bytes;
+};
+__global__ __launch_bounds__(256) void cl_stem3d_kernel(const ClStem3Args a) {
+    constexpr int W = 64, RP = (W + 2) * 16, NR = 10, ROWS = 4 * NR, EP = 64 + 16;      // 4 depth planes x 10 input rows; transpose image: 32 pixels x (32 channels + pad)
+    __shared__ __attribute__((aligned(16))) char smem[ROWS * RP + 4 * 32 * EP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // workgroup -> (sample, row band, output depth): ids 8 apart on one XCD; the output depths of a band are consecutive slots
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const int od = (int)(slot % (unsigned)a.OD);
+    const unsigned nb = (slot / (unsigned)a.OD) * 8u + xcd;      // (sample, band) pair
+    const int n = (int)(nb >> 3), band = (int)(nb & 7u);
+    if (n >= a.N) return;
+    const int oh0 = band * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    if (tid < 2 * ROWS) *reinterpret_cast<u32x4*>(smem + (tid >> 1) * RP + (tid & 1) * (W + 1) * 16) = u32x4{0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int r = wave; r < ROWS; r += 4) {      // LDS row r = (depth tap r / 10, input row 2 oh0 - 1 + r % 10)
+        const int kd = r / NR, ih = 2 * oh0 - 1 + (r - kd * NR);
+        const bool ok = ih >= 0 && ih < 64;
+        const uint32_t so = ok ? (uint32_t)(((int64_t)n * a.x_sn + (int64_t)(od + kd) * a.x_sd + (int64_t)ih * a.x_sh) * 2) : 0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(smem + r * RP + 16), 16, ok ? (uint32_t)(lane * a.x_sw * 2) : 0xffffffffu, so, 0, 0);
+    }
+#endif
+    cl_h8 wfrag[16][2];
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wfrag[st][h] = *reinterpret_cast<const cl_h8*>(a.wp + ((st * 32 + l31) * 32 + (2 * h + lhi) * 8));
+    cl_wait_vm<0>();
+    __syncthreads();
+    // this wave's output row oh0 + wave: lane's pixel ow = l31; tap (kd, kh, kw = 2 h + lhi) sits at LDS row kd * 10 + 2 wave + kh, pixel 2 ow + kw (LDS pixel 0 = input column -1)
+    const char* base = smem + (2 * wave) * RP + (2 * l31 + lhi) * 16;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const cl_h8 b8 = *reinterpret_cast<const cl_h8*>(base + ((st >> 2) * NR + (st & 3)) * RP + h * 32);
+            acc = CL_MFMA(wfrag[st][h], b8, acc, 0, 0, 0);
+        }
+    char* tw = smem + ROWS * RP + wave * (32 * EP);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u32x2 o;
+        o[0] = cl_pack2(cl_act(acc[4 * q], a.act, a.slope), cl_act(acc[4 * q + 1], a.act, a.slope));
+        o[1] = cl_pack2(cl_act(acc[4 * q + 2], a.act, a.slope), cl_act(acc[4 * q + 3], a.act, a.slope));
+        *reinterpret_cast<u32x2*>(tw + l31 * EP + (8 * q + 4 * lhi) * 2) = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t ybase = (uint32_t)(2 * ((int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)(oh0 + wave) * a.y_sh));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {      // 32 pixels x 4 granules
+        const int idx = it * 64 + lane, px = idx >> 2, c = idx & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(tw + px * EP + c * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, yrs, ybase + (uint32_t)(px * a.y_sw * 2 + c * 16), 0, 0);
+    }
+}
+
 struct ClTile { int bn, bm; };
 // (oc, positions) tile of a destination with OC channels.  Two more tiles exist and are OFF by default (DCV_CL_TILES: bit 0 = 128 x 256, bit 1 = 96-wide), both
 // measured neutral in round 5 (profiles/r05_ab_cl16.txt, call 7: layer table 32.6 / 32.7 / 32.6 / 32.8 ms, iteration 41.7-42.2 ms for all four settings):
@@ -1522,6 +1600,27 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     // zeros past OC — so nobody has to clear a fresh tensor's padding channels first
     const int ocs = (dst.w > 1 ? dst.sw : pad8(pl.OC)) >= pad8(pl.OC) && pl.OC % 8 ? pad8(pl.OC) : (pl.OC + 3) / 4 * 4;
     if (dst.w > 1 && dst.sw < ocs) return fail(DCV_EINVAL, "cl conv: destination pixel pitch %lld < %d stored channels", (long long)dst.sw, ocs);
+    if (thin && !accumulate && !stat && !gate) {
+        // fused 3-D stem (cl_stem3d_kernel): Conv3d(<= 8 -> 32, 4x4x4, stride (1, 2, 2), padding (0, 1, 1)) forward on 64 x 64 frames
+        static const bool no_stem = getenv("DCV_CL_NO_STEM3") != nullptr;      // A/B only
+        if (!no_stem && which == 0 && !g->transposed && g->kd == 4 && g->kh == 4 && g->kw == 4 && g->sd == 1 && g->sh == 2 && g->sw == 2 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
+            src.h == 64 && src.w == 64 && dst.h == 32 && dst.w == 32 && dst.d == src.d - 3 && pl.OC == 32 && ocs == 32 &&
+            (reinterpret_cast<uintptr_t>(src_p) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 && src.sw >= 8 && dst.sw >= 32 &&
+            cl_extent_bytes(src, 8) < (1ll << 31) && cl_extent_bytes(dst, 32) < (1ll << 31)) {
+            ClStem3Args t;
+            memset(&t, 0, sizeof(t));
+            t.x = static_cast<const cl_h*>(src_p); t.y = static_cast<cl_h*>(dst_p); t.wp = static_cast<const cl_h*>(packed);
+            t.N = src.n; t.OD = dst.d; t.act = act; t.slope = slope;
+            t.x_sn = src.sn; t.y_sn = dst.sn; t.x_sd = (int32_t)src.sd; t.x_sh = (int32_t)src.sh; t.x_sw = (int32_t)src.sw;
+            t.y_sd = (int32_t)dst.sd; t.y_sh = (int32_t)dst.sh; t.y_sw = (int32_t)dst.sw;
+            t.x_bytes = (uint32_t)cl_extent_bytes(src, 8); t.y_bytes = (uint32_t)cl_extent_bytes(dst, 32);
+            const unsigned nwg = (unsigned)(src.n * 8 * dst.d);      // (sample, band) pairs are a multiple of 8: every XCD slot sequence is whole
+            hipLaunchKernelGGL(cl_stem3d_kernel, dim3(nwg), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_stem3d_kernel (fused, thin source, " CL_HALF_NAME " channels-last)");
+            DCV_LAUNCH_CHECK();
+            return DCV_OK;
+        }
+    }
     if (thin && !accumulate && !stat) {
         // fused form (cl_widen3x3_kernel): 2-D 3x3 / stride 1 / pad 1 direct form out of a thin source on 64-wide rows, 64 or 128 destination channels
         static const bool no_fused = getenv("DCV_CL_NO_WIDEN3") != nullptr;      // A/B only

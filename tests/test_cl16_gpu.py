@@ -41,6 +41,7 @@ CASES = [
     ("conv3d_4s122_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2),
     ("conv3d_4s122_thin3_32", False, 3, 3, 32, 4, (1, 2, 2), (0, 1, 1), (16, 64, 64), 1),
     ("conv3d_4s122_thin1_32", False, 3, 1, 32, 4, (1, 2, 2), (0, 1, 1), (15, 64, 64), 1),
+    ("conv3d_4s122_thin2_32_n3", False, 3, 2, 32, 4, (1, 2, 2), (0, 1, 1), (6, 64, 64), 3),
     ("conv3d_4s122_256_1", False, 3, 256, 1, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 2),
 ]
 
@@ -87,7 +88,9 @@ def test_conv_cl16(case):
     wd = w.detach().to(DEV).requires_grad_(True)
     y = ops_cl.conv(xc, wd, ops.conv_geom(wd, s_t, p_t, tr))
     kn = native.lib().dcv_debug_last_kernel().decode()
-    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn or "cl_widen3x3" in kn), kn
+    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn or "cl_widen3x3" in kn or "cl_stem3d" in kn), kn
+    if name.startswith("conv3d_4s122_thin"):
+        assert "cl_stem3d" in kn, kn            # the fused 3-D stem form
     if name.startswith("conv2d_3s1p1_thin"):
         assert "cl_widen3x3" in kn, kn          # the fused thin-source form
     if name.startswith("convT2d_3s1p1"):

@@ -32,6 +32,7 @@ def fp16():
 CASES = [
     ("conv3d_4s122_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2),
     ("conv3d_4s122_thin2_32", False, 3, 2, 32, 4, (1, 2, 2), (0, 1, 1), (9, 32, 32), 2),
+    ("conv3d_4s122_thin3_32_stem", False, 3, 3, 32, 4, (1, 2, 2), (0, 1, 1), (6, 64, 64), 2),
     ("conv3d_4s122_256_1", False, 3, 256, 1, 4, (1, 2, 2), (0, 1, 1), (7, 8, 8), 2),
     ("conv2d_4s2p1_64_128", False, 2, 64, 128, 4, 2, 1, (16, 16), 3),
     ("convT2d_4s2p1_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3),
