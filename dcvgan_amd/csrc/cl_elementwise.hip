@@ -205,7 +205,7 @@ __device__ __forceinline__ void cl_bn_block_out(double (&s)[8][NV], const ClBnAr
 #pragma unroll
             for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int v = 0; v < NV; ++v) red[((wave * a.G + lane) * 8 + e) * NV + v] = s[e][v];
+                for (int v = 0; v < NV; ++v) red[((e * NV + v) * 4 + wave) * a.G + lane] = s[e][v];      // lane-linear: consecutive lanes, consecutive doubles (the [lane][e][v] order was a G-way bank conflict per store)
         __syncthreads();
         if ((int)threadIdx.x < a.G)
 #pragma unroll
@@ -214,7 +214,7 @@ __device__ __forceinline__ void cl_bn_block_out(double (&s)[8][NV], const ClBnAr
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     double t = 0.0;
-                    for (int w = 0; w < 4; ++w) t += red[((w * a.G + g) * 8 + e) * NV + v];
+                    for (int w = 0; w < 4; ++w) t += red[((e * NV + v) * 4 + w) * a.G + g];
                     if (c < a.C) a.partial[((int64_t)blockIdx.x * a.C + c) * NV + v] = t;
                 }
             }
