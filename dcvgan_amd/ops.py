@@ -188,7 +188,7 @@ def grad_target(p):
             b = getattr(p, "_dcv_bucket", None)      # data parallel: autograd will not visit this parameter's AccumulateGrad node (nothing is returned for it), so
             b = b() if b is not None else None       # the bucket's "a backward has produced gradients" mark is set here instead of by its post-accumulate hook
             if b is not None:
-                b.dirty = True
+                b.note_inplace(p)
             return g.data_ptr()
         return None
     a = getattr(p, "_dcv_acc", None)
@@ -318,6 +318,9 @@ class _Conv(Function):
                 slot = getattr(w, "_dcv_grad_slot", None)
                 if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _Conv._epoch[0]:
                     w._dcv_slot_epoch = _Conv._epoch[0]
+                    b = getattr(w, "_dcv_bucket", None)
+                    if b is not None and b() is not None:
+                        b().before_slot_write(w)      # a collective of the previous backward may still be reading this slice (GradBucket(overlap=True))
                     dw = slot.detach()
                 else:
                     dw = _empty(w.shape, w.device)

@@ -302,6 +302,9 @@ class _ConvCl(Function):
                 slot = getattr(w, "_dcv_grad_slot", None)       # data parallel: the parameter's slice of its bucket's flat buffer (optim.GradBucket), as on the fp32 path
                 if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _o._Conv._epoch[0] and _o._OWN_ACCUMULATION:
                     w._dcv_slot_epoch = _o._Conv._epoch[0]
+                    b = getattr(w, "_dcv_bucket", None)
+                    if b is not None and b() is not None:
+                        b().before_slot_write(w)
                     dw = slot.detach()
                 else:
                     dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)

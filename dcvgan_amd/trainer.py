@@ -46,11 +46,15 @@ def build_loss(cfg: StepConfig):
     return Lm.AdversarialLoss() if cfg.loss == "adversarial-loss" else Lm.HingeLoss()
 
 
-def build_optimizers(cfg: StepConfig, models, data_parallel: bool = False):
+def build_optimizers(cfg: StepConfig, models, data_parallel: bool = False, overlap: Optional[bool] = None):
     """train.py:169-176.  Data parallel: the optimisers stepped after the same backward share one gradient
-    bucket — D phase (trainer.py:319-322) and G phase (trainer.py:356-359) — so an iteration has two collectives."""
+    bucket — D phase (trainer.py:319-322) and G phase (trainer.py:356-359) — so an iteration has two collectives.
+    `overlap` (default: the environment's DCV_DP_OVERLAP, else off): per-model chunks whose collectives start from the hook of the chunk's last gradient, on a
+    communication stream, while the rest of the backward runs (optim.GradBucket(overlap=True)); off by default until an N > 1 run has measured it."""
     opts = {}
-    buckets = {"D": optim.GradBucket(), "G": optim.GradBucket()} if data_parallel else None
+    if overlap is None:
+        overlap = os.environ.get("DCV_DP_OVERLAP") is not None
+    buckets = {"D": optim.GradBucket(overlap=overlap), "G": optim.GradBucket(overlap=overlap)} if data_parallel else None
     for name in MODEL_NAMES:
         o = optim.Adam(models[name].parameters(), lr=cfg.lr[name], betas=(0.5, 0.999), weight_decay=cfg.decay[name])
         opts[name] = optim.DataParallelAdam(o, buckets["D" if name.endswith("dis") else "G"]) if data_parallel else o

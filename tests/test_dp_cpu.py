@@ -203,3 +203,74 @@ def test_bench_launcher_fails_loudly_without_gpus():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode not in (0, 2) and p.stdout.strip() == "" and "rank" in p.stderr, (p.returncode, p.stderr[-500:])
     assert time.time() - t0 < 120
+
+
+def _worker_overlap(rank, world, port, q):
+    """GradBucket(overlap=True) over gloo: per-model chunks; the first backward is reduced at the step (nothing recorded yet), from the second on every chunk's collective
+    is launched from the hook of its last gradient — during the backward — and the step only waits; gradients and parameters equal the non-overlapped bucket's bit for bit;
+    a parameter without gradient keeps a zero slice; a changed arrival set falls back to the step-time reduction for that chunk."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dcvgan_amd import optim
+
+    def build(overlap):
+        torch.manual_seed(5)
+        a = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.Tanh(), torch.nn.Linear(40, 8))       # "ggen"
+        b = torch.nn.Sequential(torch.nn.Linear(8, 64), torch.nn.Tanh(), torch.nn.Linear(64, 3))       # "cgen"
+        bucket = optim.GradBucket(overlap=overlap, merge_bytes=64)
+        oa = optim.DataParallelAdam(_SGD(a.parameters(), 0.05), bucket)
+        ob = optim.DataParallelAdam(_SGD(b.parameters(), 0.05), bucket)
+        return a, b, bucket, oa, ob
+
+    ok = True
+    res = {}
+    for overlap in (False, True):
+        a, b, bucket, oa, ob = build(overlap)
+        gd = torch.Generator().manual_seed(100 + rank)
+        early = []
+        for it in range(4):
+            for n in (a, b):
+                n.zero_grad()
+            x = torch.randn(5, 6, generator=gd)
+            (b(a(x)) ** 2).mean().backward()
+            early.append(bucket.early)
+            oa.step(); ob.step(); oa.step()
+        res[overlap] = torch.cat([p.detach().reshape(-1) for n in (a, b) for p in n.parameters()]).clone()
+        if overlap:
+            ok &= len(bucket._chunks) == 2                                  # one chunk per model
+            ok &= early == [0, 2, 4, 6]                                      # iteration 1: reduced at the step; then both chunks launched DURING each backward
+            ok &= bucket.collectives == 2 * 4 and bucket.reductions == 4
+        else:
+            ok &= len(bucket._chunks) == 1 and bucket.collectives == 4 and bucket.early == 0
+    ok &= torch.equal(res[False], res[True])                                 # two ranks: the sum of two numbers is the same in one message or in two
+    allw = [None] * world
+    dist.all_gather_object(allw, res[True].numpy())
+    ok &= all((w == allw[0]).all() for w in allw)                            # replicas identical
+    # a backward that skips model b's second layer (another arrival set): no early launch for that chunk, still correct
+    a, b, bucket, oa, ob = build(True)
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(rank))
+    for n in (a, b):
+        n.zero_grad()
+    (b(a(x)) ** 2).mean().backward(); oa.step(); ob.step()
+    for n in (a, b):
+        n.zero_grad()
+    e0 = bucket.early
+    (b[0](a(x)) ** 2).mean().backward()                                      # b[2] gets no gradient this time
+    ok &= bucket.early == e0 + 1                                             # model a's chunk went early, model b's did not
+    oa.step(); ob.step()
+    ok &= float(b[2].weight._dcv_grad_slot.abs().max()) == 0.0 and bool(torch.isfinite(bucket._flat).all())
+    q.put((rank, bool(ok), early))
+    dist.destroy_process_group()
+
+
+def test_dp_overlap_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ps = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+    assert all(g[1] for g in got), got

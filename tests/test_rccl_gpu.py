@@ -27,3 +27,20 @@ def test_rccl_world1_bucket_allreduce():
     if d:
         os.makedirs(d, exist_ok=True)
         json.dump(r, open(os.path.join(d, "rccl_world1_bucket.json"), "w"), indent=1)
+
+
+def test_rccl_world1_overlapped_chunks():
+    """optim.GradBucket(overlap=True) on the card: chunk collectives launched during the backward on the communication stream, Adam and the next backward ordered behind
+    them; three StepRunner iterations equal the step-time reduction and the plain run bit for bit (tools/rccl_overlap_probe.py)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_overlap_probe.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["backend"] == "nccl" and r["world_size"] == 1
+    assert r["sync_equals_plain"] and r["overlap_equals_sync"], r
+    assert r["sync"]["early"] == 0 and r["overlap"]["early"] >= 2, r          # from the second iteration on, chunks go out during the backward
+    assert sum(r["overlap"]["chunks"]) >= 3, r                                    # G bucket: ggen and cgen apart; D bucket: the small models merged
+    d = os.environ.get("DCV_REPORT_DIR")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        json.dump(r, open(os.path.join(d, "rccl_world1_overlap.json"), "w"), indent=1)
