@@ -264,7 +264,8 @@ __device__ __forceinline__ void gather_epilogue(const GatherArgs& a, const f32x1
     const bool accumulate = a.accumulate != 0;
     const float slope = a.slope;
     const uint32_t y_sc4 = (uint32_t)a.y_sc * 4u;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_off + (int64_t)n0 * a.y_sn, 0, 0x80000000u, 0x00020000);
+    // (p_pad2 = 0x5701, DCV_DEBUG_NOSTORE=1: an empty descriptor — every store is dropped by the range check; timing experiments only: what the epilogue's stores cost)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_off + (int64_t)n0 * a.y_sn, 0, a.p_pad2 == 0x5701 ? 0u : 0x80000000u, 0x00020000);
     uint32_t voff[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) voff[j] = out_voffset(a, m0 + mcol0 + j * 32 + l31, n0, lhi, y_sc4);
@@ -2487,6 +2488,8 @@ static int flush_packs(const float* w, const PackArgs& packs, int n, int kmax, i
 }
 
 static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& tc, int KS, int OC, hipStream_t stream) {
+    static const bool nostore = getenv("DCV_DEBUG_NOSTORE") != nullptr;
+    if (nostore) for (int i = 0; i < n; ++i) pend.c[i].p_pad2 = 0x5701;
     for (int i = n; i < 4; ++i) pend.c[i] = pend.c[0];
     {   // grid.x comes in as the largest class's (oc tiles x position tiles); see the kernel's id -> tile mapping
         const unsigned tiles_oc = (unsigned)(pend.c[0].OCp / tc.bn);

@@ -65,6 +65,15 @@ def cl_empty(shape, device, pitch: Optional[int] = None, zero: bool = False) -> 
     return store.permute(*perm)[:, :c]
 
 
+def _check_out_view(y: torch.Tensor, what: str) -> None:
+    """Kernels that produce a CL16 tensor write whole 8-channel groups (zeros past C).  A destination VIEW whose channel count is not a multiple of 8 is therefore only
+    legal when nothing live follows it inside its pixel: a fresh tensor, or the trailing member of a ConcatBuffer (which marks it).  Anything else — a middle slice of a
+    hand-made buffer — would get zeros written over its neighbour's first channels, silently: refused here."""
+    if y.shape[1] % 8 and not getattr(y, "_dcv_trailing", False):
+        raise N.NativeError(f"{what}: out= view with {y.shape[1]} channels (not a multiple of 8) that is not the trailing slice of its buffer: the kernels write whole "
+                            "8-channel groups and would overwrite the channels behind it")
+
+
 def is_cl(t: torch.Tensor) -> bool:
     return t.dtype == torch.bfloat16 or t.dtype == torch.float16
 
@@ -96,6 +105,8 @@ class _FromF32(Function):
     @staticmethod
     def forward(ctx, x, out=None):
         N._require(x, "from_f32 input")
+        if out is not None:
+            _check_out_view(out.t, "from_f32")
         y = cl_empty(x.shape, x.device) if out is None else out.t.detach()
         xd, yd = dims5(x), dims5(y)
         check(_fn("from_f32")(ptr(x), C.byref(xd), ptr(y), C.byref(yd), stream_ptr()), "dcv_cl_from_f32")
@@ -227,6 +238,8 @@ class _ConvCl(Function):
         if x.shape[1] != g.cin:
             raise N.NativeError(f"conv: input has {x.shape[1]} channels, module expects {g.cin}")
         shape = _out_shape(g, x)
+        if out is not None:
+            _check_out_view(out.t, "conv")
         y = cl_empty(shape, x.device) if out is None else out.t.detach()
         if tuple(y.shape) != tuple(shape):
             raise N.NativeError(f"out= has shape {tuple(y.shape)}, expected {tuple(shape)}")
@@ -330,6 +343,8 @@ class _BnActCl(Function):
         _req(x, "bn input")
         L = lib()
         Cn = x.shape[1]
+        if out is not None:
+            _check_out_view(out.t, "bn_act")
         y = cl_empty(x.shape, x.device) if out is None else out.t.detach()
         stats = torch.empty((2, Cn), dtype=torch.float32, device=x.device)
         xd, yd = dims5(x), dims5(y)
@@ -384,6 +399,7 @@ class ConcatBuffer:
             raise N.NativeError("ConcatBuffer: the first member's channel count must be a multiple of 8 (16-byte aligned second slice)")
         self.buf = cl_empty((n, ca + cb) + tuple(spatial), device, zero=bool((ca + cb) % 8))
         self.first, self.second = self.buf[:, :ca], self.buf[:, ca:]
+        self.second._dcv_trailing = True          # nothing live behind it inside a pixel (only the buffer's own padding): may have any channel count (_check_out_view)
         from .ops import GradSlot, _SKIP_ACCUMULATE
         self.slot = GradSlot() if _SKIP_ACCUMULATE else None
 

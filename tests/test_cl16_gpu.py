@@ -442,3 +442,18 @@ def test_gated_skip_gradient_cl16():
     for n in ga:
         assert rel(ga[n], gb[n]) < 2e-2, (n, rel(ga[n], gb[n]))
     assert rel(ga["inconv.main.0.weight"], gb["inconv.main.0.weight"]) < 1e-2
+
+
+def test_out_view_that_is_not_a_multiple_of_8_channels_must_be_trailing():
+    """the kernels write whole 8-channel groups; a destination view with C % 8 != 0 followed by live channels would have them zeroed silently: refused."""
+    from dcvgan_amd import native, ops, ops_cl
+    native.lib()
+    buf = ops_cl.cl_empty((2, 32, 8, 8), DEV, zero=True)
+    x = ops_cl.from_f32(torch.randn(2, 8, 8, 8, device=DEV))
+    w = torch.randn(12, 8, 3, 3, device=DEV) * 0.1
+    g = ops.conv_geom(w, (1, 1), (1, 1), False)
+    with pytest.raises(native.NativeError):
+        ops_cl.conv(x, w, g, out=buf[:, 8:20])                    # 12 channels in the middle of a 32-channel pixel
+    cat = ops_cl.ConcatBuffer(2, 8, 12, (8, 8), DEV)              # ... the trailing member of a concatenation may have any width
+    y = ops_cl.conv(x, w, g, out=cat.second)
+    assert y.shape[1] == 12 and torch.isfinite(y.float()).all()

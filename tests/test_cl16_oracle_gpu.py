@@ -17,12 +17,12 @@ from tests import goldenio as G
 pytestmark = pytest.mark.gpu
 FIX = ["fullwidth_isogd_depth.npz", "fullwidth_surreal_depth1.npz", "fullwidth_isogd_flow.npz"]
 # bars (measured maxima over the three configs on MI355X in round 5 beside them)
-BAR = {"xg": 2e-2,        # geometry video, relative L2 (measured 4.4e-3 ... 6.5e-3)
-       "xc": 5e-2,        # colour video (measured 1.4e-2 ... 2.2e-2)
-       "logits": 1.5e-1,  # the three discriminators' logits (measured 2.4e-2 ... 8.9e-2)
-       "loss": 5e-2,      # generator loss, relative (measured 2e-4 ... 1.1e-2)
-       "cos": 0.80,       # cosine of each model's flattened parameter gradient with the oracle's (measured 0.90 ... 0.998)
-       "norm": 0.25}      # | ||g|| / ||g_oracle|| - 1 | per model (measured <= 0.08)
+BAR = {"xg": 2e-2,        # geometry video, relative L2 (measured 6.9e-3 / 8.0e-3 / 7.1e-3: isogd-flow / surreal-depth1 / isogd-depth)
+       "xc": 5e-2,        # colour video (measured 2.0e-2 ... 2.3e-2)
+       "logits": 1.5e-1,  # the three discriminators' logits, the worst of them (measured 5.3e-2 ... 8.0e-2)
+       "loss": 5e-2,      # generator loss, relative (measured 3.8e-4 ... 1.4e-3)
+       "cos": 0.80,       # cosine of each model's flattened parameter gradient with the oracle's (measured: ggen 0.917-0.950, cgen 0.934-0.964, discriminators 0.995-0.9999)
+       "norm": 0.25}      # | ||g|| / ||g_oracle|| - 1 | per model (measured <= 0.035)
 
 
 def _rel(a, b):
@@ -122,7 +122,8 @@ def test_cl16_batch_split_identity_b100(name):
     names = ("xg", "xc", "yi", "yv", "yg")
     errs = {k: _rel(a, b) for k, a, b in zip(names, big, small)}
     print(name, errs)
-    # the same arithmetic per sample, in other tiles: sums of the same bf16 products in another order, then one bf16 rounding — differences of a rounding of the result
+    # the same arithmetic per sample whatever tile it lands in: every output element's K sum has one fixed order (no atomics, no batch-dependent split in the forward
+    # kernels), so the two passes agree BIT FOR BIT (measured: 0.0 on every quantity of both configs); held to 1e-6
     assert all(torch.isfinite(a).all() for a in big)
     for k, v in errs.items():
-        assert v < (2e-2 if k in ("xg", "xc") else 6e-2), (k, v)
+        assert v < 1e-6, (k, v)

@@ -41,6 +41,7 @@ def main():
             buckets = list({id(o.bucket): o.bucket for o in opts.values()}.values())
             for b in buckets:
                 b._force_layout = True
+                b.merge_bytes = 128 << 10      # reduced-width models: keep them in chunks of their own (at full width ggen / cgen are 15 / 40 MB)
                 b.reduce = (lambda bb: (lambda force=False: optim.GradBucket.reduce(bb, force=True)))(b)      # a world of one reduces nothing by itself
         runner = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg), sync_losses=True)
         losses = [runner.step(xc, xg, 2 + i) for i in range(3)]

@@ -42,11 +42,14 @@ if CL:
     zero = sum(int((g == 0).sum()) for g in gs); tot = sum(g.numel() for g in gs)
     print(f"{MODE} B={B}: largest pre-BatchNorm magnitude {peak:.2f}; parameter-gradient elements exactly zero {zero} of {tot} ({zero / tot:.2%}); all finite {all(bool(torch.isfinite(g).all()) for g in gs)}")
 print("shapes", tuple(yv.shape), tuple(yg.shape), "finite", bool(torch.isfinite(yv).all() and torch.isfinite(yg).all()))
+for _ in range(8):      # the clocks of a freshly started process are not the ones it holds under load: warm up before timing (3 timed steps right after start read up to 4x high)
+    step()
+NT = 10
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(3):
+for _ in range(NT):
     step()
 e1.record(); e1.synchronize()
-ms = e0.elapsed_time(e1) / 3
+ms = e0.elapsed_time(e1) / NT
 gf = 3 * (55.1 + 13.6) * B   # fwd + dgrad + wgrad, SURVEY §8(d)
 print(f"{MODE} B={B}: {ms:.2f} ms per fwd+bwd, ~{gf / ms:.1f} TFLOP/s, {B / ms * 1e3:.1f} clips/s, peak mem {torch.cuda.max_memory_allocated() / 1e9:.2f} GB")
