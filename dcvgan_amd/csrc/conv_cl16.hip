@@ -137,6 +137,10 @@ struct ClGatherArgs {
     // a tensor of the destination's shape and strides — and applied in the epilogue: dx = (accumulate ? dx : 0) + conv^T(dy, w), then dx *= (gate > 0 ? 1 : gate_slope)
     const cl_h* gate;
     float gate_slope; int32_t pad3;
+    // split-K (few position tiles, long K loop: the latent layers at 1x1 ... 4x4 positions per image): blockIdx.y handles K steps [y ks_per, (y + 1) ks_per) and leaves
+    // raw fp32 partial sums in slab[y][position][OCp]; cl_splitk_reduce_kernel adds the slabs in order (bitwise reproducible), applies the activation and stores bf16
+    float* slab;
+    int32_t ks_per, slab_m;      // K steps per split; positions per slab (position tiles x BM)
 };
 struct ClGatherPack {
     ClGatherArgs c[4];
@@ -287,7 +291,8 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
             }                                                                                                                 \
         } else {                                                                                                              \
             /* the per-lane offsets change with the TAP only: (re)formed at a tap's first channel block; the channel block rides on the scalar offset */ \
-            if (nx_cb == 0 || ragged) {                                                                                       \
+            if (nx_cb == 0 || ragged || xvo_stale) {      /* (xvo_stale: a split-K share may start in the middle of a tap) */             \
+                xvo_stale = false;                                                                                            \
                 const uint32_t to_ = to_cur;                                                                                  \
                 _Pragma("unroll") for (int s = 0; s < XPT; ++s) {                                                             \
                     /* granules past the operand's own channels (a 16- or 24-channel slice of a wider buffer) are padding, not the neighbour's data */ \
@@ -304,11 +309,12 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(wb_ + (j * NT + wave * 64) * 16), 16, wvo[j], st_ * wstep, 0, 0); \
     }
 #else
-#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; (void)xvo; (void)nx_tap; (void)nx_cb; (void)ragged; (void)to_cur; (void)toff_v; }
+#define CL_ISSUE(STEP, BUF) { (void)wstep; (void)wvo; (void)xbase; (void)xmask; (void)xchunk; (void)xrs; (void)wrs; (void)toff_l; (void)xvo; (void)nx_tap; (void)nx_cb; (void)ragged; (void)to_cur; (void)toff_v; (void)xvo_stale; }
 #endif
     // issue state of the thick form: K steps are issued in order, so (tap, channel block) of the next one are counters, not a division per step
     [[maybe_unused]] uint32_t xvo[XPT];
     [[maybe_unused]] int nx_tap = 0, nx_cb = 0;
+    [[maybe_unused]] bool xvo_stale = true;
     // tap offsets: lane t keeps toff[t]; the loop picks the next tap's with v_readlane (a scalar load of toff[tap] at every tap boundary stalled the wave ~250 cycles)
     [[maybe_unused]] const int toff_v = a.toff[lane];
     [[maybe_unused]] uint32_t to_cur = (uint32_t)a.toff[0];
@@ -343,16 +349,21 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
             boff[j][s] = (uint32_t)(row * 64 + (((2 * s + lhi) ^ ((row >> 2) & 3)) << 4));
         }
 
-    const int nst = a.nsteps;
+    // K steps of this workgroup: all of them, or split blockIdx.y's share
+    const int st0 = a.slab ? (int)blockIdx.y * a.ks_per : 0;
+    const int nst = a.slab ? min(a.nsteps, st0 + a.ks_per) : a.nsteps;
+    if (st0 > 0) {      // issue state of the thick form at an arbitrary first step
+        if constexpr (!THIN) { nx_tap = st0 / a.cblk; nx_cb = st0 - nx_tap * a.cblk; to_cur = (uint32_t)__builtin_amdgcn_readlane(toff_v, nx_tap & 63); }
+    }
     // vector-memory instructions one K step costs THIS wave (the weight tile of a 32-channel tile is 128 granules: waves 0-1 only)
     const bool wfull = (BN * 4) % NT == 0 || wave * 64 + NT * (WPT - 1) < BN * 4;
-    CL_ISSUE(0, 0)
-    if constexpr (NS >= 3) { if (nst > 1) CL_ISSUE(1, 1) }
-    if constexpr (NS >= 4) { if (nst > 2) CL_ISSUE(2, 2) }
+    CL_ISSUE(st0, 0)
+    if constexpr (NS >= 3) { if (nst > st0 + 1) CL_ISSUE(st0 + 1, 1) }
+    if constexpr (NS >= 4) { if (nst > st0 + 2) CL_ISSUE(st0 + 2, 2) }
     [[maybe_unused]] const unsigned long long ts_loop = CL_T();
     int buf = 0;
     [[maybe_unused]] int nbuf = NS - 1;      // stage of step st; stage the step issued now lands in
-    for (int st = 0; st < nst; ++st) {
+    for (int st = st0; st < nst; ++st) {
         [[maybe_unused]] const unsigned long long t0_ = CL_T();
         // step st's granules have landed: all but the (NS - 2) younger steps' instructions of this wave are done
         if constexpr (NS == 2) cl_wait_vm<0>();
@@ -392,6 +403,23 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
     }
     [[maybe_unused]] const unsigned long long ts_epi = CL_T();
 
+    if (a.slab) {
+        // split-K: raw partial sums, [split][position][OCp] fp32 — an accumulator quad is 4 consecutive channels of one position = one 16-byte store
+        float* __restrict__ sl = a.slab + (int64_t)blockIdx.y * a.slab_m * a.OCp;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + (wm * TM + j) * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TOC; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int oc = oc0 + (woc * TOC + i) * 32 + 8 * q + 4 * lhi;
+                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(sl + (int64_t)m * a.OCp + oc) = v;
+                }
+        }
+        return;
+    }
     // ---- epilogue
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
     const int act = a.act;
@@ -551,6 +579,35 @@ __global__ __launch_bounds__(64 * WOC * WM, WOC * WM == 4 ? 2 : 1) void cl_gathe
 #endif
 }
 #undef CL_ISSUE
+
+// split-K: y[position][8 channels] = act(sum over the splits, in order); one thread per 16-byte destination granule
+__global__ __launch_bounds__(256) void cl_splitk_reduce_kernel(const ClGatherArgs a, int KS) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int G = a.y_c >> 3;
+    if (i >= (int64_t)a.M * G) return;
+    const int m = (int)(i / G), oc = (int)(i - (int64_t)m * G) * 8;
+    const float* p = a.slab + (int64_t)m * a.OCp + oc;
+    const int64_t stride = (int64_t)a.slab_m * a.OCp;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int k = 0; k < KS; ++k) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p + k * stride), hi = *reinterpret_cast<const f32x4*>(p + k * stride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
+    }
+    const uint32_t n = fdiv((uint32_t)m, a.div_sp);
+    uint32_t r = (uint32_t)m - n * a.div_sp.div;
+    const uint32_t od = fdiv(r, a.div_hw);
+    r -= od * a.div_hw.div;
+    const uint32_t oh = fdiv(r, a.div_w);
+    const uint32_t ow = r - oh * a.div_w.div;
+    cl_h* y = a.y + ((int64_t)n * a.y_sn + (int64_t)od * a.y_sd + (int64_t)oh * a.y_sh + (int64_t)ow * a.y_sw + a.y_off) + oc;
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = cl_pack2(cl_act(v[2 * q], a.act, a.slope), cl_act(v[2 * q + 1], a.act, a.slope));
+    *reinterpret_cast<u32x4*>(y) = o;
+}
 
 // Wp[cls][step][OCp][32]: thick: step = tap * cblk + cb, k = channel cb * 32 + kk;  thin: step covers taps 4 step .. 4 step + 3, k = (tap & 3) * 8 + channel
 struct ClPackArgs {
@@ -1343,6 +1400,23 @@ static void cl_launch_tile(const ClTile tc, const ClGatherPack& pk, bool thin, d
 // (Round 5, measured and not instantiated: NS = 3 and 4 — two / three K steps in flight behind counted vmcnt waits, at 3 or 2 workgroups per CU instead of 4 —
 // ran the surreal-depth1 layer table in 39.5 / 41.3 ms against 37.9 and the iteration in 49.3 / 51.4 ms against 47.2 (profiles/r05_ab_cl16.txt): what bounds the
 // loop is the issue cost of the LDS-DMA instructions, 4-5 per wave and K step against 8 MFMAs, not the distance of the prefetch; fewer waves per SIMD lose more.)
+// split-K plan of a single-class, thick, plain (no statistics / accumulate / gate) call whose output has at most 4 positions per SAMPLE (the latent layers: 1x1 and 2x2
+// outputs, M = 1-4 x batch positions for K loops of 128-384 steps).  The decision and the split count depend on the geometry only, never on the batch: every output
+// element's K sum keeps one fixed order whatever the batch size (tests/test_cl16_oracle_gpu.py::test_cl16_batch_split_identity_b100 holds B = 100 against B = 16 bit for
+// bit; a tile-count rule, tried first, broke exactly that).  KS = 0: not split.
+struct ClSplitK { int KS, ks_per; size_t slab_bytes; int slab_m; };
+static ClSplitK cl_splitk_plan(int ncls, bool thin, int64_t M, int per_sample, int OCp, int nsteps, const ClTile tc, int ocs) {
+    ClSplitK r = {0, 0, 0, 0};
+    static const bool off = getenv("DCV_CL_NO_SPLITK") != nullptr;      // A/B only
+    if (off || ncls != 1 || thin || ocs % 8 || per_sample > 4 || nsteps < 64) return r;
+    const int KS = std::min(8, nsteps / 8);
+    const int64_t tiles_m = (M + tc.bm - 1) / tc.bm;
+    r.ks_per = (nsteps + KS - 1) / KS;
+    r.KS = (nsteps + r.ks_per - 1) / r.ks_per;
+    r.slab_m = (int)(tiles_m * tc.bm);
+    r.slab_bytes = (size_t)r.KS * r.slab_m * OCp * sizeof(float);
+    return r;
+}
 template <int TOC, int TM, int WOC, int WM>
 static void cl_launch_gather(const ClGatherPack& pk, bool thin, dim3 grid, hipStream_t s) {
     if (thin) hipLaunchKernelGGL((cl_gather_kernel<TOC, TM, WOC, WM, true, 2>), grid, dim3(64 * WOC * WM), 0, s, pk);
@@ -1439,7 +1513,19 @@ size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv
 size_t dcv_cl_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {
     ClPlan pl;
     if (!g || !x || !y || (which != 0 && which != 1) || cl_make_plan(which, g, x, y, &pl) != DCV_OK) return 0;
-    if (!cl_thin_out(pl, g)) return 256;
+    if (!cl_thin_out(pl, g)) {
+        // split-K slabs of a single-class call with few position tiles (cl_splitk_plan; the run splits only if this much workspace is there)
+        size_t slab = 0;
+        if (pl.cls.size() == 1) {
+            const dcv_dims5& dst = (which == 0) ? *y : *x;
+            const ClClass& c = pl.cls[0];
+            const ClTile tc = cl_pick_tile(pl.OC);
+            const int OCp = (pl.OC + tc.bn - 1) / tc.bn * tc.bn, T = c.t[0].n * c.t[1].n * c.t[2].n;
+            const int nsteps = cl_thin(pl.RC) ? (T + 3) / 4 : T * (cl_cp(pl.RC) / 32);
+            slab = cl_splitk_plan(1, cl_thin(pl.RC), (int64_t)dst.n * c.o_ext[0] * c.o_ext[1] * c.o_ext[2], c.o_ext[0] * c.o_ext[1] * c.o_ext[2], OCp, nsteps, tc, 8).slab_bytes;
+        }
+        return 256 + slab;
+    }
     const dcv_dims5& src = (which == 0) ? *x : *y;
     return (size_t)src.n * src.d * src.h * src.w * cl_pitch(g->kd * g->kh * g->kw * pl.OC) * 2 + 512;
 }
@@ -1713,10 +1799,23 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
     }
     static const int dbg = getenv("DCV_CL_DEBUG") ? atoi(getenv("DCV_CL_DEBUG")) : 0;      // 1: no epilogue stores (timing experiments only)
     for (int i = 0; i < n; ++i) pk.c[i].pad2 = dbg;
+    ClSplitK sk = {0, 0, 0, 0};
+    if (!stat && !accumulate && !gate) sk = cl_splitk_plan(n, thin, pk.c[0].M, (int)pk.c[0].div_sp.div, OCp, pk.c[0].nsteps, tc, ocs);
+    if (sk.KS && (!ws || ws_bytes < sk.slab_bytes || (reinterpret_cast<uintptr_t>(ws) & 15))) sk.KS = 0;
+    if (sk.KS) { pk.c[0].slab = static_cast<float*>(ws); pk.c[0].ks_per = sk.ks_per; pk.c[0].slab_m = sk.slab_m; }
     for (int i = n; i < 4; ++i) pk.c[i] = pk.c[0];
     pk.ncls = n; pk.tiles_oc = OCp / tc.bn; pk.tiles_m = (int)maxtm;
-    const dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
+    dim3 grid((unsigned)((maxtm + 7) / 8 * 8 * pk.tiles_oc * n));
+    if (sk.KS) grid.y = (unsigned)sk.KS;
     cl_launch_tile(tc, pk, thin, grid, st);
+    if (sk.KS) {
+        DCV_LAUNCH_CHECK();
+        const int64_t tot = (int64_t)pk.c[0].M * (ocs / 8);
+        hipLaunchKernelGGL(cl_splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pk.c[0], sk.KS);
+        snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile> (1 class, split-K x %d, " CL_HALF_NAME " channels-last)", tc.bn, tc.bm, sk.KS);
+        DCV_LAUNCH_CHECK();
+        return DCV_OK;
+    }
     snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_gather_kernel<%d x %d tile%s> (%d class%s, " CL_HALF_NAME " channels-last)", tc.bn, tc.bm, thin ? ", thin" : "", n, n == 1 ? "" : "es");
     DCV_LAUNCH_CHECK();
     return DCV_OK;

@@ -388,18 +388,18 @@ def test_bn_sums_from_the_conv_epilogue_cl16(case):
     w = (torch.randn(((cin, cout) if tr else (cout, cin)) + kk, generator=g0) * 0.05).to(DEV)
     gamma = (torch.rand(cout, generator=g0) + 0.5).to(DEV); beta = (torch.randn(cout, generator=g0) * 0.1).to(DEV)
     geom = ops.conv_geom(w, ss, pp, tr)
+    box = []
+    y = ops_cl.conv(x, w, geom, bn_stats=box)
+    assert len(box) == 1 and box[0][1] > 0, "the epilogue produced no sums for this geometry"
+    y_plain = ops_cl.conv(x, w, geom)                  # without the extra epilogue (round 5: this one may take the split-K form where the position tiles are few: the
+    assert rel(y_plain.float(), y.float()) < 4e-3      # same sums in another order, equal to one bf16 rounding; bit-equal where it does not)
     res = []
-    for fused in (True, False):
-        box = [] if fused else None
-        y = ops_cl.conv(x, w, geom, bn_stats=box)
-        if fused:
-            assert len(box) == 1 and box[0][1] > 0, "the epilogue produced no sums for this geometry"
+    for fused in (True, False):                        # the SAME convolution output through BatchNorm with the epilogue's sums and with BatchNorm's own pass
         rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
         nbt = torch.zeros((), dtype=torch.int64, device=DEV)
         z = ops_cl.bn_act(y, gamma, beta, rm, rv, True, ops.ACT_LEAKY, 0.2, partials=box[0] if fused else None, num_batches_tracked=nbt)
         res.append((y.float().clone(), z.float().clone(), rm.clone(), rv.clone(), int(nbt)))
     (y1, z1, rm1, rv1, n1), (y0, z0, rm0, rv0, n0) = res
-    assert torch.equal(y1, y0)                       # the convolution's own output is untouched by the extra epilogue
     assert n1 == n0 == 1
     assert rel(rm1, rm0) < 1e-6 and rel(rv1, rv0) < 1e-6, (rel(rm1, rm0), rel(rv1, rv0))
     assert rel(z1, z0) < 1e-4 and float((z1 != z0).float().mean()) < 2e-2, (rel(z1, z0), float((z1 != z0).float().mean()))
