@@ -1319,6 +1319,294 @@ __global__ __launch_bounds__(256) void cl_stem3d_kernel(const ClStem3Args a) {
     }
 }
 
+// --------------------------------------------------------------------------- //
+// Patch-staged scatter form, 2-D, 4x4 / stride 2 / padding 1 (round 5): ConvTranspose2d forward (the generators' up-sampling layers) and the data gradient of
+// Conv2d(4, 2, 1).  The tiled gather runs the four stride-parity classes as four GEMMs: every class stages its own 2 x 2 taps of the source (each source pixel goes
+// through the texture path 16 times per 64 destination channels, in half lines — tools/lds_dma_rate.hip: that path takes an LDS-DMA instruction line by line, so
+// half lines halve it), and on the layers with 16-32 K steps a workgroup spends 15-40 % of its life in prologue + epilogue (cycle stamps).  Here a workgroup owns
+// 256 source positions (8 rows of a 32-wide image ... 16 whole 4 x 4 images) and ALL FOUR classes of them = 1024 destination positions x 64 channels:
+//   * per 32-channel block the source patch with its one-pixel halo is staged ONCE (340-576 rows of 64 bytes, double-buffered across blocks); the 16 (class, tap)
+//     pairs are 9 source offsets, applied by the fragment reads (a lane's row + a per-offset constant);
+//   * the weights of a block stream through a two-slot ring in four chunks of four (class, tap) pairs x 64 channels x 32 k = 16 KB of whole lines, ordered by
+//     source offset: centre (4 classes) | up, down | left, right | the four corners — 9 activation fragment reads per 32 MFMAs instead of 16;
+//   * 8 waves, wave = 32 source positions x 64 channels x 4 classes = 128 accumulator registers; one barrier per chunk (16 MFMAs per wave), counted vmcnt waits
+//     (a chunk's weights are issued one chunk ahead, the next block's patch two to four chunks ahead);
+//   * per K block the texture path moves 22-37 KB of patch + 64 KB of weights for 512 MFMAs (~40 % of its rate at full MFMA speed), the LDS ~60 %: MFMA-bound;
+//   * epilogue through a wave-private LDS transpose: the two column classes of a destination row interleave into whole 128-byte pixels, 16-byte row-order stores;
+//     BatchNorm sums of the stored values per (patch, channel) for conv -> BatchNorm pairs, summed over the waves in a fixed order.
+// Packed weights: [oc tile][k block][chunk][pair][64 oc][32 k], granules pre-swizzled (the DMA is a linear copy).  Roofline: MFMA.
+// --------------------------------------------------------------------------- //
+struct ClPatchArgs {
+    const cl_h* x; cl_h* y; const cl_h* wp; float* stat;
+    int32_t N, H, W, C32;          // source images, extent, 32-channel K blocks
+    int32_t OCp, octiles, NI, PRI; // padded destination channels (64 octiles); images and rows of an image per patch (NI PRI W = 32 NW)
+    int32_t RI, prows, bands, npatch;   // patch rows per image = (PRI + 2)(W + 2); NI RI; H / PRI; patches
+    int32_t wlog, plog, act, y_c;  // log2 W, log2 (PRI W); channels to store
+    float slope; int32_t total;    // workgroups that have work = npatch octiles
+    int64_t x_sn, y_sn;
+    int32_t x_sh, x_sw, y_sh, y_sw;
+    uint32_t x_bytes, y_bytes, w_bytes, pad;
+};
+constexpr int CLP_B = 16384;      // a weight chunk
+
+// NW waves = 32 NW source positions per workgroup: 8 (one workgroup per CU) or 4 (two independent ones, which overlap one's staging and fragment reads with the other's MFMAs;
+// each stages the weight chunks itself: 2x the weight bytes through the texture path)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kernel(const ClPatchArgs a) {
+    constexpr int CLP_AMAX = (NW == 8 ? 37 : 19) * 1024;      // a patch buffer: up to 576 / 288 rows in pieces of 16
+    __shared__ __attribute__((aligned(16))) char smem[2 * CLP_AMAX + 2 * CLP_B];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    // workgroup -> (patch, oc tile): ids 8 apart (one XCD) walk a contiguous range of patches, the oc tiles of a patch next to one another
+    const unsigned per = gridDim.x >> 3;
+    const unsigned lin = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (lin >= (unsigned)a.total) return;
+    const int patch = (int)(lin / (unsigned)a.octiles), octile = (int)(lin % (unsigned)a.octiles);
+    const int img0 = (patch / a.bands) * a.NI, r0 = (patch % a.bands) * a.PRI;
+    const int W2 = a.W + 2;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<cl_h*>(a.wp), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+
+    // ---- staging roles: piece = 16 patch rows x 4 granules; wave w owns pieces w, w + NW, ... (at most 5); granule -> row g >> 2, physical chunk g & 3 holds logical chunk ^ ((row >> 2) & 3)
+    const int npiece = (a.prows + 15) >> 4;
+    const int np_w = (npiece - wave + NW - 1) / NW;      // pieces of this wave
+    uint32_t xvo[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int g = (wave + NW * j) * 64 + lane, row = g >> 2, c = (g & 3) ^ ((row >> 2) & 3);
+        uint32_t vo = 0xffffffffu;
+        if (row < a.prows) {
+            const int im = row / a.RI, rem = row - im * a.RI;
+            const int ry = rem / W2, rx = rem - ry * W2;
+            const int sy = r0 + ry - 1, sx = rx - 1, n = img0 + im;
+            if (n < a.N && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W)
+                vo = (uint32_t)(2 * ((int64_t)n * a.x_sn + (int64_t)sy * a.x_sh + (int64_t)sx * a.x_sw) + 16 * c);
+        }
+        xvo[j] = vo;
+    }
+    // ---- fragment addresses.  Activations: this lane's source position q = 32 wave + l31 -> patch row; offset (dy, dx) adds dy (W + 2) + dx rows
+    uint32_t aaddr[9][2];
+    {
+        const int q = wave * 32 + l31;
+        const int im = q >> a.plog, rem = q & ((1 << a.plog) - 1);
+        const int r = rem >> a.wlog, c = rem & (a.W - 1);
+        const int row0 = im * a.RI + (r + 1) * W2 + (c + 1);
+#pragma unroll
+        for (int o = 0; o < 9; ++o) {
+            const int row = row0 + (o / 3 - 1) * W2 + (o % 3 - 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) aaddr[o][k] = (uint32_t)(row * 64 + (((2 * k + lhi) ^ ((row >> 2) & 3)) << 4));
+        }
+    }
+    // weights: row = pair * 64 + 32 ocg + l31 of the chunk: (row >> 2) & 3 = (l31 >> 2) & 3
+    uint32_t boff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) boff[k] = (uint32_t)(l31 * 64 + (((2 * k + lhi) ^ ((l31 >> 2) & 3)) << 4));
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int S = a.C32 * 4;      // chunks
+    constexpr int BPW = 16 / NW;      // weight pieces per wave and chunk
+    const uint32_t wbase = (uint32_t)octile * (uint32_t)a.C32 * 4u * (uint32_t)CLP_B + (uint32_t)(BPW * wave) * 1024u + (uint32_t)lane * 16u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CLP_ISSUE_A(J, CB, BUF)                                                                                                       \
+    if ((J) < np_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void_t*)(smem + (BUF) * CLP_AMAX + (wave + NW * (J)) * 1024), 16, xvo[J], (CB) * 64, 0, 0);
+#define CLP_ISSUE_B(STEP)                                                                                                             \
+    {                                                                                                                                 \
+        char* d_ = smem + 2 * CLP_AMAX + ((STEP) & 1) * CLP_B + (BPW * wave) * 1024;                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < BPW; ++i_)                                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void_t*)(d_ + i_ * 1024), 16, wbase + (uint32_t)i_ * 1024u, (STEP) * CLP_B, 0, 0); \
+    }
+#else
+#define CLP_ISSUE_A(J, CB, BUF) { (void)xvo; (void)np_w; (void)xrs; }
+#define CLP_ISSUE_B(STEP) { (void)wbase; (void)wrs; }
+#endif
+#define CLP_A(O) av = *reinterpret_cast<const cl_h8*>(Ab + aaddr[O][k]);
+#define CLP_CT(CT, CLS)                                                                                                               \
+    {                                                                                                                                 \
+        const cl_h8 b0_ = *reinterpret_cast<const cl_h8*>(Bb + boff[k] + (CT) * 4096), b1_ = *reinterpret_cast<const cl_h8*>(Bb + boff[k] + (CT) * 4096 + 2048); \
+        acc[CLS][0] = CL_MFMA(b0_, av, acc[CLS][0], 0, 0, 0);                                                                         \
+        acc[CLS][1] = CL_MFMA(b1_, av, acc[CLS][1], 0, 0, 0);                                                                         \
+    }
+    // raw barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it while LDS-DMAs are pending and drain the patch pieces the counted waits leave in flight
+    // (the wave's own fragment reads are done: their MFMAs have consumed them; the memory clobbers keep the compiler from moving LDS accesses or DMAs across)
+#define CLP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // what the wave may leave in flight at the top of a chunk: the patch pieces it issued AFTER the weights in the previous chunk
+    auto wait_top = [&](int left) {
+        if (left <= 0) cl_wait_vm<0>();
+        else if (left == 1) cl_wait_vm<1>();
+        else if (left == 2) cl_wait_vm<2>();
+        else cl_wait_vm<3>();
+    };
+    CLP_ISSUE_A(0, 0, 0) CLP_ISSUE_A(1, 0, 0) CLP_ISSUE_A(2, 0, 0) CLP_ISSUE_A(3, 0, 0) CLP_ISSUE_A(4, 0, 0)
+    CLP_ISSUE_B(0)
+    const int n0 = np_w < 3 ? np_w : 3, n1 = np_w - n0;      // patch pieces issued in chunk 0 / chunk 1 of a block
+    for (int cb = 0; cb < a.C32; ++cb) {
+        const char* Ab = smem + (cb & 1) * CLP_AMAX;
+        const bool nextb = cb + 1 < a.C32;
+        cl_h8 av;
+        // ---- chunk 0: the centre offset, all four classes
+        {
+            cl_wait_vm<0>();
+            CLP_BARRIER();
+            CLP_ISSUE_B(cb * 4 + 1)
+            if (nextb) { CLP_ISSUE_A(0, cb + 1, (cb + 1) & 1) CLP_ISSUE_A(1, cb + 1, (cb + 1) & 1) CLP_ISSUE_A(2, cb + 1, (cb + 1) & 1) }
+            const char* Bb = smem + 2 * CLP_AMAX;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { CLP_A(4) CLP_CT(0, 0) CLP_CT(1, 1) CLP_CT(2, 2) CLP_CT(3, 3) }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- chunk 1: one row up (row classes 0), one row down (row classes 1)
+        {
+            wait_top(nextb ? n0 : 0);
+            CLP_BARRIER();
+            CLP_ISSUE_B(cb * 4 + 2)
+            if (nextb) { CLP_ISSUE_A(3, cb + 1, (cb + 1) & 1) CLP_ISSUE_A(4, cb + 1, (cb + 1) & 1) }
+            const char* Bb = smem + 2 * CLP_AMAX + CLP_B;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { CLP_A(1) CLP_CT(0, 0) CLP_CT(1, 1) CLP_A(7) CLP_CT(2, 2) CLP_CT(3, 3) }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- chunk 2: one column left (column classes 0), one column right (column classes 1)
+        {
+            wait_top(nextb ? n1 : 0);
+            CLP_BARRIER();
+            CLP_ISSUE_B(cb * 4 + 3)
+            const char* Bb = smem + 2 * CLP_AMAX;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { CLP_A(3) CLP_CT(0, 0) CLP_CT(1, 2) CLP_A(5) CLP_CT(2, 1) CLP_CT(3, 3) }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // ---- chunk 3: the corners
+        {
+            cl_wait_vm<0>();
+            CLP_BARRIER();
+            const int st = cb * 4 + 3;
+            if (st + 1 < S) CLP_ISSUE_B(st + 1)
+            const char* Bb = smem + 2 * CLP_AMAX + CLP_B;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { CLP_A(0) CLP_CT(0, 0) CLP_A(2) CLP_CT(1, 1) CLP_A(6) CLP_CT(2, 2) CLP_A(8) CLP_CT(3, 3) }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+#undef CLP_BARRIER
+#undef CLP_ISSUE_A
+#undef CLP_ISSUE_B
+#undef CLP_A
+#undef CLP_CT
+    __syncthreads();      // every wave has left the K loop: the staging buffers are free
+
+    // ---- epilogue: per destination-row class py, the wave's 64 destination pixels (source position p, column class px) -> [2 p + px][64 channels] in its own LDS
+    // window, out as 16-byte granules in pixel order (for a 32-wide source row: one whole destination row, 8 KB contiguous)
+    constexpr int EP = 128 + 16;
+    char* tw = smem + wave * (64 * EP + 256);
+    uint32_t* rowoff = reinterpret_cast<uint32_t*>(tw + 64 * EP);
+    {
+        const int q = wave * 32 + (lane >> 1), px = lane & 1;
+        const int im = q >> a.plog, rem = q & ((1 << a.plog) - 1);
+        const int r = rem >> a.wlog, c = rem & (a.W - 1);
+        const int n = img0 + im;
+        rowoff[lane] = n < a.N ? (uint32_t)(2 * ((int64_t)n * a.y_sn + (int64_t)(2 * (r0 + r)) * a.y_sh + (int64_t)(2 * c + px) * a.y_sw)) : 0xffffffffu;
+    }
+    const int act = a.act;
+    const float slope = a.slope;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int ocg = 0; ocg < 2; ++ocg)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x16& t = acc[py * 2 + px][ocg];
+                    u32x2 o;
+                    o[0] = cl_pack2(cl_act(t[4 * q4], act, slope), cl_act(t[4 * q4 + 1], act, slope));
+                    o[1] = cl_pack2(cl_act(t[4 * q4 + 2], act, slope), cl_act(t[4 * q4 + 3], act, slope));
+                    *reinterpret_cast<u32x2*>(tw + (2 * l31 + px) * EP + (ocg * 32 + 8 * q4 + 4 * lhi) * 2) = o;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes (and rowoff), before its lanes read one another's
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 64 + lane, j = idx >> 3, c = idx & 7;
+            const uint32_t ro = rowoff[j];
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tw + j * EP + c * 16);
+            const uint32_t vo = (ro != 0xffffffffu && octile * 64 + 8 * c < a.y_c) ? ro + (uint32_t)(py * a.y_sh * 2 + (octile * 64 + 8 * c) * 2) : 0xffffffffu;
+            __builtin_amdgcn_raw_buffer_store_b128(v, yrs, vo, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next row class overwrites the image
+    }
+    if (a.stat) {
+        // {sum, sum of squares} of the STORED values per channel over this patch's 1024 destination positions (rows of images past N hold exact zeros): half-wave sums by
+        // DPP, the NW waves meet in LDS and are added in wave order: stat[patch][OCp][2]
+        __syncthreads();
+        float* sred = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int ocg = 0; ocg < 2; ++ocg)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int cls = 0; cls < 4; ++cls) { const float v = cl_round(acc[cls][ocg][r]); s1 += v; s2 += v * v; }
+                s1 = cl_half_wave_sum(s1);
+                s2 = cl_half_wave_sum(s2);
+                if (l31 == 31) {
+                    const int ocl = ocg * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+                    sred[(wave * 64 + ocl) * 2] = s1;
+                    sred[(wave * 64 + ocl) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += sred[w * 128 + tid];
+            a.stat[((int64_t)patch * a.OCp + octile * 64) * 2 + tid] = t;
+        }
+    }
+}
+
+// weights of cl_patch_convt_kernel: [oc tile][k block][chunk][pair][64 oc][32 k]; (chunk, pair) -> (class, filter row, filter column) as the kernel's chunks use them;
+// the four 16-byte granules of a row stored at position ^ ((oc >> 2) & 3)
+struct ClPackPatchArgs {
+    cl_h* wp;
+    int32_t OC, OCp, C, C32, KW, pad;
+    int64_t ws_o, ws_r;
+};
+__global__ __launch_bounds__(256) void cl_pack_patch_kernel(const float* __restrict__ w, const ClPackPatchArgs pa) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)pa.OCp * pa.C32 * 16 * 32;
+    if (i >= tot) return;
+    const int kk = (int)(i & 31), ocl = (int)((i >> 5) & 63), ct = (int)((i >> 11) & 3), ch = (int)((i >> 13) & 3);
+    const int64_t rest = i >> 15;
+    const int cb = (int)(rest % pa.C32), octile = (int)(rest / pa.C32);
+    // logical k of this physical slot
+    const int gl = (kk >> 3) ^ ((ocl >> 2) & 3), k = gl * 8 + (kk & 7);
+    // (chunk, pair) -> class (py, px) and source offset (dy, dx); filter index: row class 0: dy 0 -> 1, -1 -> 3; row class 1: dy 0 -> 2, +1 -> 0 (columns alike)
+    int py, px, dy, dx;
+    if (ch == 0) { py = ct >> 1; px = ct & 1; dy = 0; dx = 0; }
+    else if (ch == 1) { py = ct >> 1; px = ct & 1; dy = py ? 1 : -1; dx = 0; }
+    else if (ch == 2) { px = ct >> 1; py = ct & 1; dy = 0; dx = px ? 1 : -1; }
+    else { py = ct >> 1; px = ct & 1; dy = py ? 1 : -1; dx = px ? 1 : -1; }
+    const int ky = dy == 0 ? (py ? 2 : 1) : (py ? 0 : 3), kx = dx == 0 ? (px ? 2 : 1) : (px ? 0 : 3);
+    const int oc = octile * 64 + ocl, c = cb * 32 + k;
+    float v = 0.f;
+    if (oc < pa.OC && c < pa.C) v = w[(int64_t)oc * pa.ws_o + (int64_t)c * pa.ws_r + ky * pa.KW + kx];
+    pa.wp[i] = (cl_h)v;
+}
+
 struct ClTile { int bn, bm; };
 // (oc, positions) tile of a destination with OC channels.  Two more tiles exist and are OFF by default (DCV_CL_TILES: bit 0 = 128 x 256, bit 1 = 96-wide), both
 // measured neutral in round 5 (profiles/r05_ab_cl16.txt, call 7: layer table 32.6 / 32.7 / 32.6 / 32.8 ms, iteration 41.7-42.2 ms for all four settings):
@@ -1385,6 +1673,41 @@ static bool cl_thin_out(const ClPlan& pl, const dcv_conv_geom* g) {
     return pl.OC <= 8 && !cl_thin(pl.RC) && T * pl.OC <= 64 && !off;
 }
 static inline int cl_pitch(int c) { return c <= 8 ? 8 : (c + 31) / 32 * 32; }
+
+// cl_patch_convt_kernel's plan.  Decided on SHAPES only (the packed weights carry its layout behind the tiled gather's, so a call the run-time conditions exclude —
+// accumulate, gate, a misaligned view — still has the other form's tiles)
+struct ClPatchPlan { bool ok; int NP, NI, PRI, RI, prows, bands, npatch, wlog, plog, C32, OCp, octiles; size_t pack_bytes; };
+static ClPatchPlan cl_patch_plan(int which, const dcv_conv_geom* g, const ClPlan& pl, const dcv_dims5& src, const dcv_dims5& dst) {
+    ClPatchPlan r;
+    memset(&r, 0, sizeof(r));
+    static const bool off = getenv("DCV_CL_NO_PATCH") != nullptr;      // A/B only
+    const bool direct = (which == 0 && !g->transposed) || (which == 1 && g->transposed);
+    if (off || direct || g->kd != 1 || g->kh != 4 || g->kw != 4 || g->sd != 1 || g->sh != 2 || g->sw != 2 || g->pd != 0 || g->ph != 1 || g->pw != 1) return r;
+    if (src.d != 1 || dst.d != 1 || dst.h != 2 * src.h || dst.w != 2 * src.w) return r;
+    const int W = src.w, H = src.h;
+    if ((W != 4 && W != 8 && W != 16 && W != 32) || H < 1 || (H & (H - 1))) return r;
+    if (pl.RC < 32 || pl.RC % 32 || pl.OC < 64 || pl.OC % 8) return r;      // (destination channels past the last whole 64: zero weights, never stored)
+    static const int np_env = getenv("DCV_CL_PATCH_NP") ? atoi(getenv("DCV_CL_PATCH_NP")) : 0;      // A/B only: 256 = eight waves, one workgroup per CU
+    const int NP = np_env == 256 ? 256 : 128;
+    r.NP = NP;
+    if (H * W >= NP) { r.NI = 1; r.PRI = NP / W; if (r.PRI < 1 || H % r.PRI) return r; }
+    else { r.NI = NP / (H * W); r.PRI = H; }
+    r.RI = (r.PRI + 2) * (W + 2); r.prows = r.NI * r.RI;
+    if (r.prows > (NP == 256 ? 576 : 288)) return r;
+    r.bands = H / r.PRI;
+    r.npatch = (src.n + r.NI - 1) / r.NI * r.bands;
+    for (r.wlog = 0; (1 << r.wlog) < W; ++r.wlog) {}
+    for (r.plog = 0; (1 << r.plog) < r.PRI * W; ++r.plog) {}
+    r.C32 = pl.RC / 32; r.OCp = (pl.OC + 63) / 64 * 64; r.octiles = r.OCp / 64;
+    r.pack_bytes = (size_t)r.octiles * r.C32 * 4 * CLP_B;
+    r.ok = true;
+    return r;
+}
+static size_t cl_generic_pack_bytes(const ClPlan& pl) {
+    size_t tot = 0;
+    for (const ClClass& c : pl.cls) tot += cl_class_pack_bytes(c, pl.RC, pl.OC);
+    return align_up(tot, 256);
+}
 
 static int cl_check_tensor(const dcv_dims5& d, const char* tag) {
     if (d.c > 1 && d.sc != 1) return fail(DCV_EINVAL, "%s: channels-last tensor expected (channel stride 1, got %lld)", tag, (long long)d.sc);
@@ -1504,9 +1827,9 @@ size_t dcv_cl_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv
         const ClTile tc = cl_pick_tile(OCg);
         return align_up((size_t)(cl_cp(pl.RC) / 32) * ((OCg + tc.bn - 1) / tc.bn * tc.bn) * 64, 256) + 256;
     }
-    size_t tot = 0;
-    for (const ClClass& c : pl.cls) tot += cl_class_pack_bytes(c, pl.RC, pl.OC);
-    return tot + 256;
+    // (+ the patch-staged form's tiles behind the tiled gather's, where the shapes allow that kernel: cl_patch_plan)
+    const ClPatchPlan pp = cl_patch_plan(which, g, pl, which == 0 ? *x : *y, which == 0 ? *y : *x);
+    return cl_generic_pack_bytes(pl) + (pp.ok ? pp.pack_bytes : 0) + 256;
 }
 
 // scratch a forward / backward-data call needs (the Z tensor of the thin-destination form; 0 otherwise)
@@ -1578,6 +1901,18 @@ int dcv_cl_pack_weights(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_di
     pa.ncls = n;
     hipLaunchKernelGGL(cl_pack_kernel, dim3((unsigned)((maxtot + 255) / 256), (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), w, pa);
     DCV_LAUNCH_CHECK();
+    const ClPatchPlan pp = cl_patch_plan(which, g, pl, which == 0 ? *x : *y, which == 0 ? *y : *x);
+    if (pp.ok) {
+        const size_t o2 = cl_generic_pack_bytes(pl);
+        if (o2 + pp.pack_bytes > bytes) return fail(DCV_EWORKSPACE, "cl_pack_weights: buffer too small");
+        ClPackPatchArgs pq;
+        memset(&pq, 0, sizeof(pq));
+        pq.wp = reinterpret_cast<cl_h*>(static_cast<char*>(packed) + o2);
+        pq.OC = pl.OC; pq.OCp = pp.OCp; pq.C = pl.RC; pq.C32 = pp.C32; pq.KW = pl.KW; pq.ws_o = pl.ws_o; pq.ws_r = pl.ws_r;
+        const int64_t tot = (int64_t)pp.OCp * pp.C32 * 16 * 32;
+        hipLaunchKernelGGL(cl_pack_patch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, pq);
+        DCV_LAUNCH_CHECK();
+    }
     return DCV_OK;
 }
 
@@ -1726,6 +2061,33 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
             if (pl.OC == 128) hipLaunchKernelGGL((cl_widen3x3_kernel<4>), dim3(nwg), dim3(256), 0, st3, t);
             else hipLaunchKernelGGL((cl_widen3x3_kernel<2>), dim3(nwg), dim3(256), 0, st3, t);
             snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_widen3x3_kernel<%d> (fused, thin source, " CL_HALF_NAME " channels-last)", pl.OC / 32);
+            DCV_LAUNCH_CHECK();
+            return DCV_OK;
+        }
+    }
+    if (!thin && !accumulate && !gate) {
+        // patch-staged scatter form (cl_patch_convt_kernel): all four stride-parity classes of a 4x4 / stride-2 layer from one staged source patch
+        const ClPatchPlan pp = cl_patch_plan(which, g, pl, src, dst);
+        const int64_t xb2 = cl_extent_bytes(src, Cp), yb2 = cl_extent_bytes(dst, ocs);
+        if (pp.ok && ocs == pl.OC && (reinterpret_cast<uintptr_t>(src_p) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst_p) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(packed) & 15) == 0 && src.sw >= Cp && dst.sw >= pl.OC && xb2 < (1ll << 31) && yb2 < (1ll << 31) && pp.pack_bytes < (1ull << 31)) {
+            ClPatchArgs t;
+            memset(&t, 0, sizeof(t));
+            t.x = static_cast<const cl_h*>(src_p); t.y = static_cast<cl_h*>(dst_p);
+            t.wp = reinterpret_cast<const cl_h*>(static_cast<const char*>(packed) + cl_generic_pack_bytes(pl));
+            t.N = src.n; t.H = src.h; t.W = src.w; t.C32 = pp.C32; t.OCp = pp.OCp; t.octiles = pp.octiles; t.NI = pp.NI; t.PRI = pp.PRI;
+            t.RI = pp.RI; t.prows = pp.prows; t.bands = pp.bands; t.npatch = pp.npatch; t.wlog = pp.wlog; t.plog = pp.plog; t.act = act; t.y_c = pl.OC;
+            t.slope = slope; t.total = pp.npatch * pp.octiles;
+            t.x_sn = src.sn; t.y_sn = dst.sn; t.x_sh = (int32_t)src.sh; t.x_sw = (int32_t)src.sw; t.y_sh = (int32_t)dst.sh; t.y_sw = (int32_t)dst.sw;
+            t.x_bytes = (uint32_t)xb2; t.y_bytes = (uint32_t)yb2; t.w_bytes = (uint32_t)pp.pack_bytes;
+            if (stat && which == 0 && act == DCV_ACT_NONE && (size_t)pp.npatch * pp.OCp * 2 * sizeof(float) <= stat_bytes) {
+                t.stat = stat;
+                if (nparts) *nparts = pp.npatch;
+                if (pitch) *pitch = pp.OCp;
+            }
+            if (pp.NP == 256) hipLaunchKernelGGL((cl_patch_convt_kernel<8>), dim3((unsigned)((t.total + 7) / 8 * 8)), dim3(512), 0, static_cast<hipStream_t>(stream), t);
+            else hipLaunchKernelGGL((cl_patch_convt_kernel<4>), dim3((unsigned)((t.total + 7) / 8 * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), t);
+            snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_patch_convt_kernel<%d waves> (4 classes from one staged patch, %d x %d source, " CL_HALF_NAME " channels-last)", pp.NP / 32, src.h, src.w);
             DCV_LAUNCH_CHECK();
             return DCV_OK;
         }

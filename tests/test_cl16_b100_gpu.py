@@ -16,23 +16,23 @@ S3, P3 = (1, 2, 2), (0, 1, 1)
 # name, transposed, cin, cout, kernel, stride, padding, input shape, expected kernel family (forward, data gradient)
 LAYERS = [
     ("ggen96.0_convT_50_768", True, 50, 768, (4, 4), (1, 1), (0, 0), (1600, 50, 1, 1), ("cl_gather", "cl_gather")),
-    ("ggen96.3_convT_768_384", True, 768, 384, (4, 4), (2, 2), (1, 1), (1600, 768, 4, 4), ("cl_gather", "cl_gather")),
-    ("ggen96.6_convT_384_192", True, 384, 192, (4, 4), (2, 2), (1, 1), (1600, 384, 8, 8), ("cl_gather", "cl_gather")),
-    ("ggen96.9_convT_192_96", True, 192, 96, (4, 4), (2, 2), (1, 1), (1600, 192, 16, 16), ("cl_gather", "cl_gather")),
+    ("ggen96.3_convT_768_384", True, 768, 384, (4, 4), (2, 2), (1, 1), (1600, 768, 4, 4), ("cl_patch_convt", "cl_gather")),
+    ("ggen96.6_convT_384_192", True, 384, 192, (4, 4), (2, 2), (1, 1), (1600, 384, 8, 8), ("cl_patch_convt", "cl_gather")),
+    ("ggen96.9_convT_192_96", True, 192, 96, (4, 4), (2, 2), (1, 1), (1600, 192, 16, 16), ("cl_patch_convt", "cl_gather")),
     ("ggen96.12_convT_96_1", True, 96, 1, (4, 4), (2, 2), (1, 1), (1600, 96, 32, 32), ("cl_col2im", "thin")),
     ("ggen.12_convT_64_2_flow", True, 64, 2, (4, 4), (2, 2), (1, 1), (1600, 64, 32, 32), ("cl_col2im", "thin")),
     ("cgen.in_conv3_1_64", False, 1, 64, (3, 3), (1, 1), (1, 1), (1600, 1, 64, 64), ("cl_widen3x3", "cl_thin3x3")),
     ("cgen.in_conv3_2_64_flow", False, 2, 64, (3, 3), (1, 1), (1, 1), (1600, 2, 64, 64), ("cl_widen3x3", "cl_thin3x3")),
-    ("cgen.down0_conv_64_64", False, 64, 64, (4, 4), (2, 2), (1, 1), (1600, 64, 64, 64), ("64 x 256", "64 x 256")),
-    ("cgen.down1_conv_64_128", False, 64, 128, (4, 4), (2, 2), (1, 1), (1600, 64, 32, 32), ("128 x 128", "64 x 256")),
-    ("cgen.down3_conv_256_256", False, 256, 256, (4, 4), (2, 2), (1, 1), (1600, 256, 8, 8), ("128 x 128", "128 x 128")),
+    ("cgen.down0_conv_64_64", False, 64, 64, (4, 4), (2, 2), (1, 1), (1600, 64, 64, 64), ("64 x 256", "cl_patch_convt")),
+    ("cgen.down1_conv_64_128", False, 64, 128, (4, 4), (2, 2), (1, 1), (1600, 64, 32, 32), ("128 x 128", "cl_patch_convt")),
+    ("cgen.down3_conv_256_256", False, 256, 256, (4, 4), (2, 2), (1, 1), (1600, 256, 8, 8), ("128 x 128", "cl_patch_convt")),
     ("cgen.up0_convT_266_256", True, 266, 256, (4, 4), (2, 2), (1, 1), (1600, 266, 1, 1), ("128 x 128", "128 x 128")),
-    ("cgen.up2_convT_512_256", True, 512, 256, (4, 4), (2, 2), (1, 1), (1600, 512, 4, 4), ("128 x 128", "128 x 128")),
-    ("cgen.up4_convT_256_64", True, 256, 64, (4, 4), (2, 2), (1, 1), (1600, 256, 16, 16), ("64 x 256", "128 x 128")),
-    ("cgen.up5_convT_128_64", True, 128, 64, (4, 4), (2, 2), (1, 1), (1600, 128, 32, 32), ("64 x 256", "128 x 128")),
+    ("cgen.up2_convT_512_256", True, 512, 256, (4, 4), (2, 2), (1, 1), (1600, 512, 4, 4), ("cl_patch_convt", "128 x 128")),
+    ("cgen.up4_convT_256_64", True, 256, 64, (4, 4), (2, 2), (1, 1), (1600, 256, 16, 16), ("cl_patch_convt", "128 x 128")),
+    ("cgen.up5_convT_128_64", True, 128, 64, (4, 4), (2, 2), (1, 1), (1600, 128, 32, 32), ("cl_patch_convt", "128 x 128")),
     ("cgen.out_convT3_128_3", True, 128, 3, (3, 3), (1, 1), (1, 1), (1600, 128, 64, 64), ("cl_thin3x3", "cl_widen3x3")),
     ("idis.c_conv_3_32", False, 3, 32, (4, 4), (2, 2), (1, 1), (100, 3, 64, 64), ("thin", "cl_col2im")),
-    ("idis.5_conv_128_256", False, 128, 256, (4, 4), (2, 2), (1, 1), (100, 128, 16, 16), ("128 x 128", "128 x 128")),
+    ("idis.5_conv_128_256", False, 128, 256, (4, 4), (2, 2), (1, 1), (100, 128, 16, 16), ("128 x 128", "cl_patch_convt")),
     ("idis.9_conv_256_1", False, 256, 1, (4, 4), (2, 2), (1, 1), (100, 256, 8, 8), ("cl_col2im", "thin")),
     ("vdis.g_conv3d_1_32", False, 1, 32, (4, 4, 4), S3, P3, (100, 1, 16, 64, 64), ("thin", "cl_col2im")),
     ("vdis.g_conv3d_2_32_flow", False, 2, 32, (4, 4, 4), S3, P3, (100, 2, 16, 64, 64), ("thin", "cl_gather")),
@@ -43,7 +43,7 @@ LAYERS = [
     ("gdis.1_conv3d_1_32", False, 1, 32, (4, 4, 4), S3, P3, (100, 1, 15, 64, 64), ("thin", "cl_col2im")),
     ("gdis.5_conv3d_32_64", False, 32, 64, (4, 4, 4), S3, P3, (100, 32, 12, 32, 32), ("64 x 256", "32 x 256")),
     ("gdis.9_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (100, 64, 9, 16, 16), ("128 x 128", "64 x 256")),
-    ("isogd70_cgen.up5_convT_128_64", True, 128, 64, (4, 4), (2, 2), (1, 1), (1120, 128, 32, 32), ("64 x 256", "128 x 128")),
+    ("isogd70_cgen.up5_convT_128_64", True, 128, 64, (4, 4), (2, 2), (1, 1), (1120, 128, 32, 32), ("cl_patch_convt", "128 x 128")),
     ("isogd70_vdis.1_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (70, 64, 13, 32, 32), ("128 x 128", "64 x 256")),
 ]
 

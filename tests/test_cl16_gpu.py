@@ -88,7 +88,7 @@ def test_conv_cl16(case):
     wd = w.detach().to(DEV).requires_grad_(True)
     y = ops_cl.conv(xc, wd, ops.conv_geom(wd, s_t, p_t, tr))
     kn = native.lib().dcv_debug_last_kernel().decode()
-    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn or "cl_widen3x3" in kn or "cl_stem3d" in kn), kn
+    assert y.dtype == torch.bfloat16 and ("cl_gather" in kn or "cl_thin3x3" in kn or "cl_widen3x3" in kn or "cl_stem3d" in kn or "cl_patch_convt" in kn), kn
     if name.startswith("conv3d_4s122_thin"):
         assert "cl_stem3d" in kn, kn            # the fused 3-D stem form
     if name.startswith("conv2d_3s1p1_thin"):

@@ -1,5 +1,6 @@
 """Host enqueue time of one G+D iteration against its GPU time (is the host ever the bottleneck?).
-usage: python3 tools/host_time.py [config]   -> per iteration: host ms (step() returns), wall ms (after synchronize)"""
+usage: python3 tools/host_time.py [config [precision [profile]]]   -> per iteration: host ms (step() returns), wall ms (after synchronize);
+precision bf16cl = the 16-bit channels-last path; a third argument adds a cProfile of three iterations (top functions by own time)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +9,9 @@ from dcvgan_amd.configs import CONFIGS
 
 cfg = CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "isogd-depth"]
 dev = torch.device("cuda:0")
+if len(sys.argv) > 2 and sys.argv[2] == "bf16cl":
+    from dcvgan_amd import ops_cl
+    ops_cl.enable(True)
 torch.manual_seed(0)
 models = trainer.build_models(cfg, dev)
 opts = trainer.build_optimizers(cfg, models)
@@ -25,3 +29,15 @@ for i in range(5):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"iteration {i}: host {1e3 * (t1 - t0):.1f} ms, wall {1e3 * (t2 - t0):.1f} ms")
+
+if len(sys.argv) > 3:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for i in range(3):
+        run.step(xc, xg, i)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(40)
