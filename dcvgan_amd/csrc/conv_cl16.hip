@@ -693,37 +693,47 @@ struct ClWgradArgs {
     int32_t tiles_d, gblocks;    // dense-channel tiles; 128-channel blocks of the gathered tensor (1 when GCp <= 128)
     int32_t gcb8, ntpt;          // 16-byte chunks per tap in a tile (GCB / 8); taps per tile (128 / GCB)
     int32_t tiles, S;            // tiles_d x tiles_j; position splits
-    int32_t xcd_map, pad0;
+    int32_t xcd_map, wtiles;     // wtiles: workgroups per split = tiles, or ceil(tiles / 2) in the narrow form
     uint32_t d_bytes, g_bytes;
     int32_t toff[64];            // byte offset of tap t relative to a position's gbase
 };
 
 __device__ __forceinline__ int cl_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+// NARROW (dense operand of at most 64 channels: the 64-channel layers' and the stems' gradients): rows 64-127 of the dense tile would be zeros and the two waves that own
+// them idle work — half of the MFMAs.  The workgroup takes TWO column tiles instead (images G0, G1 beside the one dense image), every wave the dense rows 0-63:
+// waves 0-1 the two column halves of G0, waves 2-3 of G1.  Slab tiles keep their [128][128] shape (rows 64-127 unwritten and never read back).
+template <bool NARROW>
 __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
-    constexpr int IMG = 32 * 256, STAGE = 2 * IMG;
+    constexpr int IMG = 32 * 256, NG = NARROW ? 2 : 1, STAGE = (1 + NG) * IMG;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wd = wave >> 1, wj = wave & 1;
+    const int wd = NARROW ? 0 : wave >> 1, wj = wave & 1, sub = NARROW ? wave >> 1 : 0;
     // workgroup -> (tile, position split): ids 8 apart run on one XCD.  The (split, tile) pairs in split-major order are cut into 8 contiguous, equally long
     // ranges, one per XCD: the workgroups an XCD runs at any time are then the tiles of one or a few position splits — they read the same dense rows and
     // overlapping gathered rows, so its L2 serves every tile after the first — and every XCD gets the same number of workgroups whatever the split count
     // (first form, splits dealt out whole: 5 of 8 XCDs idle at 3 splits, 2:1 imbalance at 12).  DCV_CL_WGRAD_FLAT: tile-major ids, round-robin (A/B)
     int tile_id, split;
     if (a.xcd_map) {
-        const unsigned W = (unsigned)a.tiles * (unsigned)a.S, q = W >> 3, r = W & 7u;
+        const unsigned W = (unsigned)a.wtiles * (unsigned)a.S, q = W >> 3, r = W & 7u;
         const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
         const unsigned item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        tile_id = (int)(item % (unsigned)a.tiles);
-        split = (int)(item / (unsigned)a.tiles);
+        tile_id = (int)(item % (unsigned)a.wtiles);
+        split = (int)(item / (unsigned)a.wtiles);
     } else {
-        tile_id = (int)(blockIdx.x % (unsigned)a.tiles);
-        split = (int)(blockIdx.x / (unsigned)a.tiles);
+        tile_id = (int)(blockIdx.x % (unsigned)a.wtiles);
+        split = (int)(blockIdx.x / (unsigned)a.wtiles);
     }
     if (split >= a.S) return;
-    const int d_t = tile_id % a.tiles_d, j_t = tile_id / a.tiles_d;
-    const int tg = j_t / a.gblocks, gb = j_t - tg * a.gblocks;
+    // (narrow: tiles_d = 1 and the work tile is the pair of column tiles 2 tile_id, 2 tile_id + 1)
+    const int d_t = NARROW ? 0 : tile_id % a.tiles_d;
+    int tgs[NG], gbs[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int j_t = NARROW ? 2 * tile_id + k : tile_id / a.tiles_d;
+        tgs[k] = j_t / a.gblocks; gbs[k] = j_t - tgs[k] * a.gblocks;
+    }
     const int m_begin = split * a.chunk;
     const int m_end = min(a.M, m_begin + a.chunk);
     const int nst = m_end > m_begin ? (m_end - m_begin + 31) / 32 : 0;
@@ -733,8 +743,8 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
 
     // staging roles: granule g = tid + 256 s -> row g >> 4 (position of the step), physical chunk g & 15, logical chunk ^ f(row)
     uint32_t dvo[2];
-    int32_t gadd[2];
-    uint32_t gtap[2];
+    int32_t gadd[NG][2];
+    uint32_t gtap[NG][2];
     int rowi[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -743,11 +753,14 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
         const int dcb = (d_t * 128 + q * 8) * 2;
         dvo[s] = dcb < a.d_cbytes ? (uint32_t)(row * a.d_pitch2 + dcb) : 0xffffffffu;
         const int tl = q / a.gcb8, cc = q - tl * a.gcb8;
-        const int tap = tg * a.ntpt + tl;
-        const int gcbyte = (gb * 128 + cc * 8) * 2;
-        const bool ok = tl < a.ntpt && tap < a.T && gcbyte < a.g_cbytes;
-        gtap[s] = ok ? (uint32_t)tap : 64u;
-        gadd[s] = ok ? a.toff[tap & 63] + gcbyte : 0;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int tap = tgs[k] * a.ntpt + tl;
+            const int gcbyte = (gbs[k] * 128 + cc * 8) * 2;
+            const bool ok = tl < a.ntpt && tap < a.T && gcbyte < a.g_cbytes;      // (a pair's second tile past the last one: tap >= T)
+            gtap[k][s] = ok ? (uint32_t)tap : 64u;
+            gadd[k][s] = ok ? a.toff[tap & 63] + gcbyte : 0;
+        }
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -760,9 +773,11 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
             const uint32_t dv_ = (mrow_ + rowi[s] < m_end) ? dvo[s] : 0xffffffffu;                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void_t*)(db_ + (s * 256 + wave * 64) * 16), 16, dv_, mrow_ * a.d_pitch2, 0, 0); \
             const ClPosEntry& e_ = s ? (E1) : (E0);                                                                           \
-            const bool ok_ = gtap[s] < 64u && ((e_.vmask >> gtap[s]) & 1ull) && (mrow_ + rowi[s] < m_end);                    \
-            const uint32_t gv_ = ok_ ? (uint32_t)(e_.gbase + gadd[s]) : 0xffffffffu;                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void_t*)(gb_ + (s * 256 + wave * 64) * 16), 16, gv_, 0, 0, 0); \
+            _Pragma("unroll") for (int k = 0; k < NG; ++k) {                                                                  \
+                const bool ok_ = gtap[k][s] < 64u && ((e_.vmask >> gtap[k][s]) & 1ull) && (mrow_ + rowi[s] < m_end);          \
+                const uint32_t gv_ = ok_ ? (uint32_t)(e_.gbase + gadd[k][s]) : 0xffffffffu;                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_void_t*)(gb_ + k * IMG + (s * 256 + wave * 64) * 16), 16, gv_, 0, 0, 0); \
+            }                                                                                                                 \
         }                                                                                                                     \
     }
 #else
@@ -793,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
                     const int cha = (wd * 64 + i * 32) / 8 + 2 * (g4 & 1) + (p >> 1);
                     const int chb = (wj * 64 + i * 32) / 8 + 2 * (g4 & 1) + (p >> 1);
                     fa[i][kk][s] = (uint32_t)(row * 256 + ((cha ^ cl_swz(row)) << 4) + 8 * (p & 1));
-                    fb[i][kk][s] = (uint32_t)(IMG + row * 256 + ((chb ^ cl_swz(row)) << 4) + 8 * (p & 1));
+                    fb[i][kk][s] = (uint32_t)(IMG + sub * IMG + row * 256 + ((chb ^ cl_swz(row)) << 4) + 8 * (p & 1));
                 }
             }
     }
@@ -834,7 +849,9 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
             e0 = n0; e1 = n1;
         }
     }
-    float* __restrict__ out = a.slab + ((int64_t)split * a.tiles + tile_id) * (128 * 128);
+    const int otile = NARROW ? 2 * tile_id + sub : tile_id;
+    if (otile >= a.tiles) return;      // (the odd tile count's last pair; after the last barrier)
+    float* __restrict__ out = a.slab + ((int64_t)split * a.tiles + otile) * (128 * 128);
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1773,7 +1790,8 @@ static bool cl_pixel_linear(const dcv_dims5& d, int64_t* pitch) {
 }
 struct ClWgradPlan {
     int64_t M;
-    int DC, GC, T, tiles_d, gblocks, gcb, ntpt, tiles_j, tiles, S, chunk;
+    int DC, GC, T, tiles_d, gblocks, gcb, ntpt, tiles_j, tiles, S, chunk, wtiles;
+    bool narrow;
     size_t tab_bytes, slab_bytes;
 };
 static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_dims5& G, ClWgradPlan* p) {
@@ -1787,11 +1805,15 @@ static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_d
     p->tiles_d = (pad8(D.c) + 127) / 128;
     p->tiles_j = (p->T + p->ntpt - 1) / p->ntpt * p->gblocks;
     p->tiles = p->tiles_d * p->tiles_j;
+    // narrow form (cl_wgrad_kernel<true>): a dense operand of <= 64 channels fills half of a 128-row tile: column tiles in pairs instead
+    static const bool no_narrow = getenv("DCV_CL_WGRAD_NO_NARROW") != nullptr;      // A/B only
+    p->narrow = !no_narrow && pad8(D.c) <= 64 && p->tiles_j >= 2;
+    p->wtiles = p->narrow ? (p->tiles_j + 1) / 2 : p->tiles;
     // position splits: ~768 workgroups (three per CU) however few tiles the op has, at least 16 K steps (512 positions) each; measured over the
     // surreal-depth1 layer table with the first reduce kernel: 13.8 ms of weight gradients per iteration at 1024, 15.9 at 2048, 20.1 at 4096 (slab traffic); with the
     // slab-order reduce, whole iterations on one box: 48.6 / 48.2 / 48.9 / 48.6 ms at 640 / 768 / 896 / 1024 (surreal-depth1), 41.8 / 41.6 / 42.1 / 42.1 (isogd-depth)
     static const int64_t target = getenv("DCV_CL_WGRAD_WGS") ? atoll(getenv("DCV_CL_WGRAD_WGS")) : 768;
-    int64_t S = (target + p->tiles - 1) / p->tiles;
+    int64_t S = (target + p->wtiles - 1) / p->wtiles;
     const int64_t maxS = std::max<int64_t>(1, p->M / 512);
     S = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S, maxS), 2048));
     int64_t chunk = ((p->M + S - 1) / S + 31) / 32 * 32;
@@ -2318,8 +2340,9 @@ static int cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const 
             a.toff[t] = (int32_t)(2 * ((int64_t)kd * G.sd + (int64_t)kh * G.sh + (int64_t)kw * G.sw));
         }
         static const bool flat = getenv("DCV_CL_WGRAD_FLAT") != nullptr;      // A/B only
-        a.tiles = p.tiles; a.S = p.S; a.xcd_map = flat ? 0 : 1;
-        hipLaunchKernelGGL(cl_wgrad_kernel, dim3((unsigned)(p.tiles * p.S)), dim3(256), 0, st, a);
+        a.tiles = p.tiles; a.S = p.S; a.xcd_map = flat ? 0 : 1; a.wtiles = p.wtiles;
+        if (p.narrow) hipLaunchKernelGGL((cl_wgrad_kernel<true>), dim3((unsigned)(p.wtiles * p.S)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((cl_wgrad_kernel<false>), dim3((unsigned)(p.wtiles * p.S)), dim3(256), 0, st, a);
         DCV_LAUNCH_CHECK();
     }
     {
@@ -2340,7 +2363,7 @@ static int cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const 
         }
         DCV_LAUNCH_CHECK();
     }
-    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles x %d position splits, " CL_HALF_NAME " channels-last)", p.tiles, p.S);
+    snprintf(g_last_kernel, sizeof(g_last_kernel), "cl_wgrad_kernel (%d tiles%s x %d position splits, " CL_HALF_NAME " channels-last)", p.tiles, p.narrow ? " in pairs, 64 dense rows" : "", p.S);
     return DCV_OK;
 }
 int dcv_cl_conv_backward_weight(const dcv_conv_geom* g, const void* x, const dcv_dims5* xd, const void* dy, const dcv_dims5* dyd, float* dw,
