@@ -691,7 +691,8 @@ struct ClWgradArgs {
     int32_t d_pitch2, d_cbytes;  // dense pixel pitch in bytes; bytes of a pixel's (padded) valid channels
     int32_t g_cbytes, T;         // same for the gathered tensor; taps
     int32_t tiles_d, gblocks;    // dense-channel tiles; 128-channel blocks of the gathered tensor (1 when GCp <= 128)
-    int32_t gcb8, ntpt;          // 16-byte chunks per tap in a tile (GCB / 8); taps per tile (128 / GCB)
+    int32_t gcb8, ntpt;          // 16-byte chunks per tap in a tile (GCB / 8); taps per tile (128 / GCB), or 0 = packed columns: the taps' GCB-wide column groups back
+                                 // to back across the tiles (channel counts that do not divide 128 — 96: four taps in three tiles instead of four)
     int32_t tiles, S;            // tiles_d x tiles_j; position splits
     int32_t xcd_map, wtiles;     // wtiles: workgroups per split = tiles, or ceil(tiles / 2) in the narrow form
     uint32_t d_bytes, g_bytes;
@@ -752,12 +753,13 @@ __global__ __launch_bounds__(256, 2) void cl_wgrad_kernel(const ClWgradArgs a) {
         rowi[s] = row;
         const int dcb = (d_t * 128 + q * 8) * 2;
         dvo[s] = dcb < a.d_cbytes ? (uint32_t)(row * a.d_pitch2 + dcb) : 0xffffffffu;
-        const int tl = q / a.gcb8, cc = q - tl * a.gcb8;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            const int tap = tgs[k] * a.ntpt + tl;
+            int tl, cc, tap;
+            if (a.ntpt) { tl = q / a.gcb8; cc = q - tl * a.gcb8; tap = tgs[k] * a.ntpt + tl; }
+            else { const int gq2 = tgs[k] * 16 + q; tap = gq2 / a.gcb8; cc = gq2 - tap * a.gcb8; tl = 0; }      // packed columns (gblocks = 1: tgs = the column tile)
             const int gcbyte = (gbs[k] * 128 + cc * 8) * 2;
-            const bool ok = tl < a.ntpt && tap < a.T && gcbyte < a.g_cbytes;      // (a pair's second tile past the last one: tap >= T)
+            const bool ok = (a.ntpt == 0 || tl < a.ntpt) && tap < a.T && gcbyte < a.g_cbytes;      // (a pair's second tile past the last one: tap >= T)
             gtap[k][s] = ok ? (uint32_t)tap : 64u;
             gadd[k][s] = ok ? a.toff[tap & 63] + gcbyte : 0;
         }
@@ -885,10 +887,11 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_kernel(const ClWgradReduc
     const int64_t tot = (int64_t)a.DC * a.GC * a.T;
     if (i >= tot) return;
     const int t = (int)(i % a.T), gc = (int)((i / a.T) % a.GC), dc = (int)(i / ((int64_t)a.T * a.GC));
-    const int d_t = dc >> 7, tg = t / a.ntpt, tl = t - tg * a.ntpt, gbk = gc >> 7;
-    const int j_t = tg * a.gblocks + gbk;
+    const int d_t = dc >> 7;
+    int j_t, vc;
+    if (a.ntpt) { const int tg = t / a.ntpt, tl = t - tg * a.ntpt; j_t = tg * a.gblocks + (gc >> 7); vc = tl * a.gcb + (gc & 127); }
+    else { const int v = t * a.gcb + gc; j_t = v >> 7; vc = v & 127; }      // packed columns
     const int tile = j_t * a.tiles_d + d_t;
-    const int vc = tl * a.gcb + (gc & 127);
     const float* p = a.slab + ((int64_t)tile * 128 + (dc & 127)) * 128 + vc;
     float s = 0.f;
     for (int k = l; k < a.S; k += lpe) s += p[(int64_t)k * a.tiles * (128 * 128)];
@@ -929,10 +932,15 @@ __global__ __launch_bounds__(256) void cl_wgrad_reduce_slab_kernel(const ClWgrad
     // slab element -> (dense channel, gathered channel, tap): the inverse of cl_wgrad_reduce_kernel's addressing
     const int tile = (int)(e >> 14), r = (int)((e >> 7) & 127), vc = (int)(e & 127);
     const int j_t = tile / a.tiles_d, d_t = tile - j_t * a.tiles_d;
-    const int tg = j_t / a.gblocks, gbk = j_t - tg * a.gblocks;
-    const int tl = vc / a.gcb, gcl = vc - tl * a.gcb;
-    const int dc = d_t * 128 + r, gc = gbk * 128 + gcl, t = tg * a.ntpt + tl;
-    if (dc >= a.DC || gc >= a.GC || tl >= a.ntpt || t >= a.T) return;
+    const int dc = d_t * 128 + r;
+    int gc, t;
+    if (a.ntpt) {
+        const int tg = j_t / a.gblocks, gbk = j_t - tg * a.gblocks;
+        const int tl = vc / a.gcb, gcl = vc - tl * a.gcb;
+        gc = gbk * 128 + gcl; t = tg * a.ntpt + tl;
+        if (tl >= a.ntpt) return;
+    } else { const int v = j_t * 128 + vc; t = v / a.gcb; gc = v - t * a.gcb; }      // packed columns
+    if (dc >= a.DC || gc >= a.GC || t >= a.T) return;
     float* o = a.dw + (int64_t)dc * a.ws_d + (int64_t)gc * a.T + t;
     *o = a.accumulate ? *o + s : s;
 }
@@ -1804,6 +1812,11 @@ static int cl_wgrad_plan(const dcv_conv_geom* g, const dcv_dims5& D, const dcv_d
     else { p->gcb = gcp; p->gblocks = 1; p->ntpt = 128 / gcp; }
     p->tiles_d = (pad8(D.c) + 127) / 128;
     p->tiles_j = (p->T + p->ntpt - 1) / p->ntpt * p->gblocks;
+    static const bool no_packed = getenv("DCV_CL_WGRAD_NO_PACKED") != nullptr;      // A/B only
+    if (!no_packed && gcp < 128 && 128 % gcp != 0) {      // packed columns: a tile's 128 columns run across tap boundaries (cl_wgrad_kernel, ntpt = 0)
+        const int tj = (p->T * gcp + 127) / 128;
+        if (tj < p->tiles_j) { p->ntpt = 0; p->tiles_j = tj; }
+    }
     p->tiles = p->tiles_d * p->tiles_j;
     // narrow form (cl_wgrad_kernel<true>): a dense operand of <= 64 channels fills half of a 128-row tile: column tiles in pairs instead
     static const bool no_narrow = getenv("DCV_CL_WGRAD_NO_NARROW") != nullptr;      // A/B only
