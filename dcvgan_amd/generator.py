@@ -79,7 +79,8 @@ class GeometricVideoGenerator(nn.Module):
             frames = ops_cl.to_f32(layers.run(self.main, ops_cl.from_f32(z.view(-1, self.dim_z, 1, 1)), self._source()))
         else:
             frames = layers.run(self.main, z.view(-1, self.dim_z, 1, 1), self._source())
-        return frames.view(batchsize, self.video_length, self.channel, 64, 64).permute(0, 2, 1, 3, 4)
+        to_video = lambda f: f.view(batchsize, self.video_length, self.channel, 64, 64).permute(0, 2, 1, 3, 4)
+        return ops_cl.carry_twin(to_video(frames), frames, to_video) if ops_cl.active() else to_video(frames)
 
     def __str__(self, name: str = "ggen") -> str:
         return json.dumps({name: {"dim_zc": self.dim_z_content, "dim_zm": self.dim_z_motion, "channel": self.channel,
@@ -209,9 +210,13 @@ class ColorVideoGenerator(nn.Module):
         B, Cg, T, H, W = xs.shape
         z = self.make_hidden(B)
         zs = z.unsqueeze(1).expand(B, T, self.dim_z, 1, 1).reshape(B * T, self.dim_z, 1, 1)
-        frames = xs.permute(0, 2, 1, 3, 4).reshape(B * T, Cg, H, W)  # a view for generator outputs
+        to_frames = lambda v: v.permute(0, 2, 1, 3, 4).reshape(B * T, Cg, H, W)  # a view for generator outputs
+        frames = to_frames(xs)
+        if ops_cl.active() and frames.data_ptr() == xs.data_ptr():      # (a copy has no twin: its bits are its own)
+            ops_cl.carry_twin(frames, xs, to_frames)
         ys = self(frames, zs)
-        return ys.view(B, T, 3, H, W).permute(0, 2, 1, 3, 4)
+        to_video = lambda f: f.view(B, T, 3, H, W).permute(0, 2, 1, 3, 4)
+        return ops_cl.carry_twin(to_video(ys), ys, to_video) if ops_cl.active() else to_video(ys)
 
     def __str__(self, name: str = "cgen") -> str:
         return json.dumps({name: {"in_ch": self.in_ch, "out_ch": self.out_ch, "dim_z": self.dim_z,

@@ -121,8 +121,34 @@ class _FromF32(Function):
         return dx, None
 
 
+# A module's fp32 output is the conversion of a CL16 tensor, and the next module converts it straight back (generator frames -> colour generator -> discriminators): the
+# fp32 tensor carries its source as `_dcv_cl_twin`, `from_f32` hands that out instead of converting, and the gradient flows from the consumer into the producer's
+# tape without the fp32 detour either (bf16 -> fp32 -> bf16 is the identity, so the forward values are the same bits).  Views made at the boundary (frames -> video)
+# carry the twin through `carry_twin`.  The fp32 tensor itself stays what the caller sees and what slicing / fp32 ops read.  DCV_CL_NO_TWINS=1: always convert (A/B).
+_TWINS = os.environ.get("DCV_CL_NO_TWINS") is None
+
+
+def twin_of(x: torch.Tensor):
+    t = getattr(x, "_dcv_cl_twin", None) if _TWINS else None
+    return t if (t is not None and t.dtype == _HALF[0] and tuple(t.shape) == tuple(x.shape)) else None
+
+
+def carry_twin(dst: torch.Tensor, src: torch.Tensor, view) -> torch.Tensor:
+    """dst = view(src) was made of an fp32 boundary tensor by pure view operations: give dst the same view of src's CL16 twin."""
+    t = twin_of(src)
+    if t is not None:
+        v = view(t)
+        if v.data_ptr() == t.data_ptr() and (v.shape[1] == 1 or v.stride(1) == 1):      # still a channels-last view of the same memory (torch made no copy)
+            dst._dcv_cl_twin = v
+    return dst
+
+
 def from_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 (any strides) -> CL16; `out`: destination view (a channel slice of a concat buffer)."""
+    if out is None:
+        t = twin_of(x)
+        if t is not None:
+            return t
     return _FromF32.apply(x, None if out is None else _Out(out))
 
 
@@ -146,8 +172,11 @@ class _ToF32(Function):
 
 
 def to_f32(x: torch.Tensor) -> torch.Tensor:
-    """CL16 -> contiguous fp32 NCDHW."""
-    return _ToF32.apply(x)
+    """CL16 -> contiguous fp32 NCDHW (which remembers x: `from_f32` of it is x again)."""
+    y = _ToF32.apply(x)
+    if _TWINS:
+        y._dcv_cl_twin = x
+    return y
 
 
 # --------------------------------------------------------------------------- #
