@@ -31,6 +31,11 @@ CASES = [
     ("conv2d_3s1p1_thin1_64", False, 2, 1, 64, 3, 1, 1, (64, 64), 2),
     ("conv2d_3s1p1_thin2_64_n9", False, 2, 2, 64, 3, 1, 1, (32, 64), 9),     # fused thin-source kernel: two bands per image, images past a multiple of 8
     ("convT2d_4s2p1_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3),
+    ("convT2d_4s2p1_64_96_w8_n5", True, 2, 64, 96, 4, 2, 1, (8, 8), 5),        # patch-staged kernel: two images per patch, an odd image count, 96 = 1.5 channel tiles
+    ("convT2d_4s2p1_96_192_w4_n11", True, 2, 96, 192, 4, 2, 1, (4, 4), 11),    # ... eight 4 x 4 images per patch, three K blocks
+    ("convT2d_4s2p1_32_64_w32", True, 2, 32, 64, 4, 2, 1, (32, 32), 2),        # ... four rows of a 32-wide image per patch, one K block
+    ("convT2d_4s2p1_64_64_h8w16", True, 2, 64, 64, 4, 2, 1, (8, 16), 3),       # ... a rectangular image
+    ("convT2d_4s2p1_64_64_h6w8", True, 2, 64, 64, 4, 2, 1, (6, 8), 2),         # a height the patch plan does not take: the tiled gather
     ("convT2d_4s2p1_288_256", True, 2, 266, 256, 4, 2, 1, (1, 1), 7),
     ("convT2d_4s1p0_latent", True, 2, 50, 128, 4, 1, 0, (1, 1), 9),
     ("convT2d_4s2p1_96_1", True, 2, 96, 1, 4, 2, 1, (32, 32), 2),
@@ -371,7 +376,7 @@ def test_iteration_cl16_is_bitwise_reproducible():
     assert torch.equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("case", [("conv2d_64_128", False, 2, 64, 128, 4, 2, 1, (16, 16), 5), ("convT2d_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3),
+@pytest.mark.parametrize("case", [("conv2d_64_128", False, 2, 64, 128, 4, 2, 1, (16, 16), 5), ("convT2d_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3), ("convT2d_64_96_w8_n5", True, 2, 64, 96, 4, 2, 1, (8, 8), 5),
                                   ("conv3d_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2), ("conv2d_thin3_32", False, 2, 3, 32, 4, 2, 1, (64, 64), 2),
                                   ("convT2d_latent_50_128", True, 2, 50, 128, 4, 1, 0, (1, 1), 9)], ids=lambda c: c[0])
 def test_bn_sums_from_the_conv_epilogue_cl16(case):
