@@ -255,6 +255,19 @@ __global__ void normal_fill_kernel(float* __restrict__ out, int64_t n, uint64_t 
         if (q * 4 + i < n) out[q * 4 + i] = z[i];
 }
 
+// `count` consecutive draws of n values each in one launch: draw j is normal_fill_kernel's output for offset + j (the generator's per-frame motion noise: 16 launches of 5 000
+// values each were 16 dependent launch latencies at the start of every generator pass)
+__global__ void normal_fill_many_kernel(float* __restrict__ out, int64_t n, int64_t count, uint64_t seed, uint64_t offset) {
+    const int64_t qpd = (n + 3) / 4, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= qpd * count) return;
+    const int64_t j = t / qpd, q = t - j * qpd;
+    float z[4];
+    normal4(seed, offset + (uint64_t)j, (uint64_t)q, z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (q * 4 + i < n) out[j * n + q * 4 + i] = z[i];
+}
+
 __global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, uint64_t seed, uint64_t offset) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q * 4 >= n) return;
@@ -1147,6 +1160,16 @@ int dcv_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, void*
     if (n == 0) return DCV_OK;
     const int64_t q = (n + 3) / 4;
     hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, seed, offset);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+int dcv_normal_fill_many(float* out, int64_t n, int64_t count, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n < 0 || count < 0) return fail(DCV_EINVAL, "normal_fill_many: bad arguments");
+    if (n == 0 || count == 0) return DCV_OK;
+    const int64_t t = (n + 3) / 4 * count;
+    if ((t + 255) / 256 >= (1ll << 31)) return fail(DCV_EUNSUPPORTED, "normal_fill_many: too many values for one launch");
+    hipLaunchKernelGGL(normal_fill_many_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), out, n, count, seed, offset);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

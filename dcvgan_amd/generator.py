@@ -9,6 +9,8 @@ path and no CPU fallback.
 """
 from __future__ import annotations
 
+import os
+
 import json
 
 import torch
@@ -21,6 +23,8 @@ from .rng import default_rng
 def _convT(cin, cout, k, s, p):
     return nn.ConvTranspose2d(cin, cout, k, s, p, bias=False)
 
+
+_NORMAL_MANY = os.environ.get("DCV_NO_NORMAL_MANY") is None      # A/B only: one launch for the per-frame motion noise
 
 class GeometricVideoGenerator(nn.Module):
     """Noise -> geometry video (depth / flow / segmentation), generator.py:11-155.
@@ -59,7 +63,12 @@ class GeometricVideoGenerator(nn.Module):
 
     def sample_z_m(self, batchsize: int) -> torch.Tensor:
         h0 = self.get_gru_initial_state(batchsize)
-        e = torch.stack([self.get_iteration_noise(batchsize) for _ in range(self.video_length)], 0)
+        # (the per-frame draws of get_iteration_noise, generator.py:57-62 of the reference, in one launch: same values, same stream position)
+        src = self._source()
+        if hasattr(src, "normal_many") and _NORMAL_MANY:
+            e = src.normal_many(self.video_length, (batchsize, self.dim_z_motion), self.device)
+        else:
+            e = torch.stack([self.get_iteration_noise(batchsize) for _ in range(self.video_length)], 0)
         r = self.recurrent
         hs = ops.gru_sequence(e, h0, r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh)  # (B, T, dm)
         return hs.view(batchsize * self.video_length, self.dim_z_motion)

@@ -78,6 +78,7 @@ _SIGS = {
     "dcv_axpby": (C.c_int, [_P, _D, C.c_float, _P, _D, C.c_float, _P, _D, _P]),
     "dcv_noise_add": (C.c_int, [_P, _D, _P, _D, C.c_float, C.c_uint64, C.c_uint64, _P]),
     "dcv_normal_fill": (C.c_int, [_P, C.c_int64, C.c_uint64, C.c_uint64, _P]),
+    "dcv_normal_fill_many": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P]),
     "dcv_dropout_mask": (C.c_int, [_P, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, _P]),
     "dcv_decode_video": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P, _P]),
     "dcv_surreal_depth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -699,6 +699,14 @@ def normal(shape, device, seed: int, offset: int) -> torch.Tensor:
     return out
 
 
+def normal_many(count: int, shape, device, seed: int, offset: int) -> torch.Tensor:
+    """(count, *shape): draw j = normal(shape, device, seed, offset + j), in one launch."""
+    out = torch.empty((int(count),) + tuple(shape), dtype=torch.float32, device=device)
+    if out.numel():
+        check(lib().dcv_normal_fill_many(ptr(out), out.numel() // int(count), int(count), int(seed), int(offset), stream_ptr()), "dcv_normal_fill_many")
+    return out
+
+
 def dropout2d_mask(n: int, c: int, p: float, device, seed: int, offset: int) -> torch.Tensor:
     out = _empty((n, c, 1, 1), device)
     N._require(out, "dropout2d_mask() output")

@@ -34,6 +34,14 @@ class PhiloxRng:
         seed, off = self._next()
         return ops.normal(shape, device, seed, off)
 
+    def normal_many(self, count: int, shape: Sequence[int], device) -> torch.Tensor:
+        """`count` consecutive draws of one shape, stacked on a new first axis: the same values and the same stream position as `count` calls of normal()."""
+        if count <= 0:
+            return torch.empty((0,) + tuple(shape), dtype=torch.float32, device=device)
+        seed, off = self._next()
+        self._counter += count - 1
+        return ops.normal_many(count, shape, device, seed, off)
+
     def noise_add(self, x: torch.Tensor, sigma: float) -> torch.Tensor:
         seed, off = self._next()
         return ops.noise_add(x, sigma, None, seed, off)
@@ -58,6 +66,9 @@ class InjectedRng:
 
     def normal(self, shape, device):
         return self._take("normal", tuple(shape), device)
+
+    def normal_many(self, count, shape, device):
+        return torch.stack([self.normal(shape, device) for _ in range(count)], 0)
 
     def noise_add(self, x, sigma):
         return ops.noise_add(x, sigma, self._take("normal", tuple(x.shape), x.device))

@@ -199,6 +199,9 @@ int dcv_noise_add(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5
                   float sigma, uint64_t seed, uint64_t offset, void* stream);
 /* out[i] = N(0,1), i < n   (latents: generator.py:85,88,104,356) */
 int dcv_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* `count` consecutive draws of n values each, out[j * n + i]: draw j holds exactly what dcv_normal_fill(.., seed, offset + j) would write (one launch for the
+ * generator's per-frame motion noise, models.py / generator.py:57-62 of the reference: video_length draws of (batch, dim_z_motion)). */
+int dcv_normal_fill_many(float* out, int64_t n, int64_t count, uint64_t seed, uint64_t offset, void* stream);
 /* Dropout2d(p) plane mask: mask[i] = Bernoulli(1-p) / (1-p), i < n = N*C (generator.py:211,248) */
 int dcv_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

@@ -269,6 +269,22 @@ def test_device_rng_moments(dev):
     assert set(m.unique().tolist()) == {0.0, 2.0} and abs(m.mean().item() - 1.0) < 2e-2
 
 
+def test_normal_many_is_the_stack_of_single_draws(dev):
+    """dcv_normal_fill_many (the generator's per-frame motion noise in one launch): draw j = the single draw at stream position offset + j, bit for bit — odd sizes
+    included (a draw's last Philox block is cut, the next draw starts a new one) — and PhiloxRng.normal_many leaves the stream where the single draws would."""
+    from dcvgan_amd import ops, rng
+    for shape, count in (((100, 10), 16), ((7, 3), 5), ((1,), 3), ((64, 10), 1)):
+        many = ops.normal_many(count, shape, dev, 4321, 17)
+        assert many.shape == (count,) + shape
+        for j in range(count):
+            assert torch.equal(many[j], ops.normal(shape, dev, 4321, 17 + j)), (shape, j)
+    a, b = rng.PhiloxRng(99), rng.PhiloxRng(99)
+    ya = a.normal_many(16, (100, 10), dev)
+    yb = torch.stack([b.normal((100, 10), dev) for _ in range(16)], 0)
+    assert torch.equal(ya, yb)
+    assert torch.equal(a.normal((5,), dev), b.normal((5,), dev))      # same stream position afterwards
+
+
 @pytest.mark.parametrize("kind", range(5))
 def test_gan_loss(dev, kind):
     from dcvgan_amd import ops
