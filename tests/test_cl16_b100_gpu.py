@@ -23,7 +23,7 @@ LAYERS = [
     ("ggen.12_convT_64_2_flow", True, 64, 2, (4, 4), (2, 2), (1, 1), (1600, 64, 32, 32), ("cl_col2im", "thin")),
     ("cgen.in_conv3_1_64", False, 1, 64, (3, 3), (1, 1), (1, 1), (1600, 1, 64, 64), ("cl_widen3x3", "cl_thin3x3")),
     ("cgen.in_conv3_2_64_flow", False, 2, 64, (3, 3), (1, 1), (1, 1), (1600, 2, 64, 64), ("cl_widen3x3", "cl_thin3x3")),
-    ("cgen.down0_conv_64_64", False, 64, 64, (4, 4), (2, 2), (1, 1), (1600, 64, 64, 64), ("64 x 256", "cl_patch_convt")),
+    ("cgen.down0_conv_64_64", False, 64, 64, (4, 4), (2, 2), (1, 1), (1600, 64, 64, 64), ("64 x 128", "cl_patch_convt")),
     ("cgen.down1_conv_64_128", False, 64, 128, (4, 4), (2, 2), (1, 1), (1600, 64, 32, 32), ("128 x 128", "cl_patch_convt")),
     ("cgen.down3_conv_256_256", False, 256, 256, (4, 4), (2, 2), (1, 1), (1600, 256, 8, 8), ("128 x 128", "cl_patch_convt")),
     ("cgen.up0_convT_266_256", True, 266, 256, (4, 4), (2, 2), (1, 1), (1600, 266, 1, 1), ("128 x 128", "128 x 128")),
@@ -37,14 +37,14 @@ LAYERS = [
     ("vdis.g_conv3d_1_32", False, 1, 32, (4, 4, 4), S3, P3, (100, 1, 16, 64, 64), ("thin", "cl_col2im")),
     ("vdis.g_conv3d_2_32_flow", False, 2, 32, (4, 4, 4), S3, P3, (100, 2, 16, 64, 64), ("thin", "cl_gather")),
     ("vdis.c_conv3d_3_32", False, 3, 32, (4, 4, 4), S3, P3, (100, 3, 16, 64, 64), ("thin", "cl_gather")),
-    ("vdis.1_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (100, 64, 13, 32, 32), ("128 x 128", "64 x 256")),
+    ("vdis.1_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (100, 64, 13, 32, 32), ("128 x 128", "64 x 128")),
     ("vdis.5_conv3d_128_256", False, 128, 256, (4, 4, 4), S3, P3, (100, 128, 10, 16, 16), ("128 x 128", "128 x 128")),
     ("vdis.9_conv3d_256_1", False, 256, 1, (4, 4, 4), S3, P3, (100, 256, 7, 8, 8), ("cl_col2im", "thin")),
     ("gdis.1_conv3d_1_32", False, 1, 32, (4, 4, 4), S3, P3, (100, 1, 15, 64, 64), ("thin", "cl_col2im")),
-    ("gdis.5_conv3d_32_64", False, 32, 64, (4, 4, 4), S3, P3, (100, 32, 12, 32, 32), ("64 x 256", "32 x 256")),
-    ("gdis.9_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (100, 64, 9, 16, 16), ("128 x 128", "64 x 256")),
+    ("gdis.5_conv3d_32_64", False, 32, 64, (4, 4, 4), S3, P3, (100, 32, 12, 32, 32), ("64 x 128", "32 x 256")),
+    ("gdis.9_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (100, 64, 9, 16, 16), ("128 x 128", "64 x 128")),
     ("isogd70_cgen.up5_convT_128_64", True, 128, 64, (4, 4), (2, 2), (1, 1), (1120, 128, 32, 32), ("cl_patch_convt", "128 x 128")),
-    ("isogd70_vdis.1_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (70, 64, 13, 32, 32), ("128 x 128", "64 x 256")),
+    ("isogd70_vdis.1_conv3d_64_128", False, 64, 128, (4, 4, 4), S3, P3, (70, 64, 13, 32, 32), ("128 x 128", "64 x 128")),
 ]
 
 
