@@ -1412,10 +1412,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kerne
         }
         xvo[j] = vo;
     }
-    // ---- fragment addresses.  Activations: this lane's source position q = 32 wave + l31 -> patch row; offset (dy, dx) adds dy (W + 2) + dx rows
-    uint32_t aaddr[9][2];
-    {
-        const int q = wave * 32 + l31;
+    // ---- wave -> (position pair pp, channel group ocg): 64 source positions (two 32-position groups) x 32 channels x 4 classes.  Per K16 slice and (class, tap) pair the
+    // wave reads ONE weight fragment for two MFMAs (first form: 32 positions x 64 channels per wave = two weight fragments per activation fragment, every wave reading the
+    // whole 16 KB chunk: 36 fragment reads per 16 MFMAs, the LDS array at its limit; now 17)
+    const int pp = wave >> 1, ocg = wave & 1;
+    // fragment addresses.  Activations: source position q = 64 pp + 32 pg + l31 -> patch row; offset (dy, dx) adds dy (W + 2) + dx rows
+    uint32_t aaddr[2][9][2];
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg) {
+        const int q = pp * 64 + pg * 32 + l31;
         const int im = q >> a.plog, rem = q & ((1 << a.plog) - 1);
         const int r = rem >> a.wlog, c = rem & (a.W - 1);
         const int row0 = im * a.RI + (r + 1) * W2 + (c + 1);
@@ -1423,15 +1428,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kerne
         for (int o = 0; o < 9; ++o) {
             const int row = row0 + (o / 3 - 1) * W2 + (o % 3 - 1);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) aaddr[o][k] = (uint32_t)(row * 64 + (((2 * k + lhi) ^ ((row >> 2) & 3)) << 4));
+            for (int k = 0; k < 2; ++k) aaddr[pg][o][k] = (uint32_t)(row * 64 + (((2 * k + lhi) ^ ((row >> 2) & 3)) << 4));
         }
     }
     // weights: row = pair * 64 + 32 ocg + l31 of the chunk: (row >> 2) & 3 = (l31 >> 2) & 3
     uint32_t boff[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) boff[k] = (uint32_t)(l31 * 64 + (((2 * k + lhi) ^ ((l31 >> 2) & 3)) << 4));
+    for (int k = 0; k < 2; ++k) boff[k] = (uint32_t)((ocg * 32 + l31) * 64 + (((2 * k + lhi) ^ ((l31 >> 2) & 3)) << 4));
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][2];      // [class][position group]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1455,12 +1460,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kerne
 #define CLP_ISSUE_A(J, CB, BUF) { (void)xvo; (void)np_w; (void)xrs; }
 #define CLP_ISSUE_B(STEP) { (void)wbase; (void)wrs; }
 #endif
-#define CLP_A(O) av = *reinterpret_cast<const cl_h8*>(Ab + aaddr[O][k]);
+#define CLP_A(O) av0 = *reinterpret_cast<const cl_h8*>(Ab + aaddr[0][O][k]); av1 = *reinterpret_cast<const cl_h8*>(Ab + aaddr[1][O][k]);
 #define CLP_CT(CT, CLS)                                                                                                               \
     {                                                                                                                                 \
-        const cl_h8 b0_ = *reinterpret_cast<const cl_h8*>(Bb + boff[k] + (CT) * 4096), b1_ = *reinterpret_cast<const cl_h8*>(Bb + boff[k] + (CT) * 4096 + 2048); \
-        acc[CLS][0] = CL_MFMA(b0_, av, acc[CLS][0], 0, 0, 0);                                                                         \
-        acc[CLS][1] = CL_MFMA(b1_, av, acc[CLS][1], 0, 0, 0);                                                                         \
+        const cl_h8 b_ = *reinterpret_cast<const cl_h8*>(Bb + boff[k] + (CT) * 4096);                                                 \
+        acc[CLS][0] = CL_MFMA(b_, av0, acc[CLS][0], 0, 0, 0);                                                                         \
+        acc[CLS][1] = CL_MFMA(b_, av1, acc[CLS][1], 0, 0, 0);                                                                         \
     }
     // raw barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it while LDS-DMAs are pending and drain the patch pieces the counted waits leave in flight
     // (the wave's own fragment reads are done: their MFMAs have consumed them; the memory clobbers keep the compiler from moving LDS accesses or DMAs across)
@@ -1478,7 +1483,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kerne
     for (int cb = 0; cb < a.C32; ++cb) {
         const char* Ab = smem + (cb & 1) * CLP_AMAX;
         const bool nextb = cb + 1 < a.C32;
-        cl_h8 av;
+        cl_h8 av0, av1;
         // ---- chunk 0: the centre offset, all four classes
         {
             cl_wait_vm<0>();
@@ -1534,17 +1539,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kerne
 #undef CLP_CT
     __syncthreads();      // every wave has left the K loop: the staging buffers are free
 
-    // ---- epilogue: per destination-row class py, the wave's 64 destination pixels (source position p, column class px) -> [2 p + px][64 channels] in its own LDS
-    // window, out as 16-byte granules in pixel order (for a 32-wide source row: one whole destination row, 8 KB contiguous)
-    constexpr int EP = 128 + 16;
-    char* tw = smem + wave * (64 * EP + 256);
-    uint32_t* rowoff = reinterpret_cast<uint32_t*>(tw + 64 * EP);
-    {
-        const int q = wave * 32 + (lane >> 1), px = lane & 1;
+    // ---- epilogue: per destination-row class py the workgroup's 64 NW destination pixels (source position p, column class px) -> [2 p + px][64 channels] in LDS (each wave
+    // its 32 channels), out as 16-byte granules in pixel order: whole 128-byte pixels (for a 32-wide source row: whole destination rows, 8 KB contiguous)
+    constexpr int EP = 128 + 16, NPX = 64 * NW;
+    uint32_t* rowoff = reinterpret_cast<uint32_t*>(smem + NPX * EP);
+    for (int j = tid; j < NPX; j += 64 * NW) {
+        const int q = j >> 1, px = j & 1;
         const int im = q >> a.plog, rem = q & ((1 << a.plog) - 1);
         const int r = rem >> a.wlog, c = rem & (a.W - 1);
         const int n = img0 + im;
-        rowoff[lane] = n < a.N ? (uint32_t)(2 * ((int64_t)n * a.y_sn + (int64_t)(2 * (r0 + r)) * a.y_sh + (int64_t)(2 * c + px) * a.y_sw)) : 0xffffffffu;
+        rowoff[j] = n < a.N ? (uint32_t)(2 * ((int64_t)n * a.y_sn + (int64_t)(2 * (r0 + r)) * a.y_sh + (int64_t)(2 * c + px) * a.y_sw)) : 0xffffffffu;
     }
     const int act = a.act;
     const float slope = a.slope;
@@ -1553,51 +1557,50 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void cl_patch_convt_kerne
 #pragma unroll
         for (int px = 0; px < 2; ++px)
 #pragma unroll
-            for (int ocg = 0; ocg < 2; ++ocg)
+            for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x16& t = acc[py * 2 + px][ocg];
+                    const f32x16& t = acc[py * 2 + px][pg];
                     u32x2 o;
                     o[0] = cl_pack2(cl_act(t[4 * q4], act, slope), cl_act(t[4 * q4 + 1], act, slope));
                     o[1] = cl_pack2(cl_act(t[4 * q4 + 2], act, slope), cl_act(t[4 * q4 + 3], act, slope));
-                    *reinterpret_cast<u32x2*>(tw + (2 * l31 + px) * EP + (ocg * 32 + 8 * q4 + 4 * lhi) * 2) = o;
+                    *reinterpret_cast<u32x2*>(smem + (2 * (pp * 64 + pg * 32 + l31) + px) * EP + (ocg * 32 + 8 * q4 + 4 * lhi) * 2) = o;
                 }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS writes (and rowoff), before its lanes read one another's
+        __syncthreads();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int idx = it * 64 + lane, j = idx >> 3, c = idx & 7;
+            const int idx = it * (64 * NW) + tid, j = idx >> 3, c = idx & 7;
             const uint32_t ro = rowoff[j];
-            const u32x4 v = *reinterpret_cast<const u32x4*>(tw + j * EP + c * 16);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(smem + j * EP + c * 16);
             const uint32_t vo = (ro != 0xffffffffu && octile * 64 + 8 * c < a.y_c) ? ro + (uint32_t)(py * a.y_sh * 2 + (octile * 64 + 8 * c) * 2) : 0xffffffffu;
             __builtin_amdgcn_raw_buffer_store_b128(v, yrs, vo, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next row class overwrites the image
+        __syncthreads();      // reads done before the next row class overwrites the image
     }
     if (a.stat) {
         // {sum, sum of squares} of the STORED values per channel over this patch's 1024 destination positions (rows of images past N hold exact zeros): half-wave sums by
-        // DPP, the NW waves meet in LDS and are added in wave order: stat[patch][OCp][2]
-        __syncthreads();
-        float* sred = reinterpret_cast<float*>(smem);
+        // DPP, the NW / 2 position pairs of a channel meet in LDS and are added in pair order: stat[patch][OCp][2]
+        float* sred = reinterpret_cast<float*>(smem);      // (the epilogue's last barrier has passed: the image is free)
 #pragma unroll
-        for (int ocg = 0; ocg < 2; ++ocg)
+        for (int r = 0; r < 16; ++r) {
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s1 = 0.f, s2 = 0.f;
+            for (int cls = 0; cls < 4; ++cls)
 #pragma unroll
-                for (int cls = 0; cls < 4; ++cls) { const float v = cl_round(acc[cls][ocg][r]); s1 += v; s2 += v * v; }
-                s1 = cl_half_wave_sum(s1);
-                s2 = cl_half_wave_sum(s2);
-                if (l31 == 31) {
-                    const int ocl = ocg * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
-                    sred[(wave * 64 + ocl) * 2] = s1;
-                    sred[(wave * 64 + ocl) * 2 + 1] = s2;
-                }
+                for (int pg = 0; pg < 2; ++pg) { const float v = cl_round(acc[cls][pg][r]); s1 += v; s2 += v * v; }
+            s1 = cl_half_wave_sum(s1);
+            s2 = cl_half_wave_sum(s2);
+            if (l31 == 31) {
+                const int ocl = ocg * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+                sred[(pp * 64 + ocl) * 2] = s1;
+                sred[(pp * 64 + ocl) * 2 + 1] = s2;
             }
+        }
         __syncthreads();
         if (tid < 128) {
             float t = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += sred[w * 128 + tid];
+            for (int w = 0; w < NW / 2; ++w) t += sred[w * 128 + tid];
             a.stat[((int64_t)patch * a.OCp + octile * 64) * 2 + tid] = t;
         }
     }

@@ -63,7 +63,7 @@ typedef struct dcv_conv_geom {
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
-/* ABI version.  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc exist (no struct changed).
+/* ABI version.  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
  * 2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
  * A host compares dcv_version() and dcv_abi_struct_sizes() with its own declarations BEFORE the first call that passes a struct
  * (dcvgan_amd/native.py does, and refuses to load on a mismatch): the library cannot see the size of what a pointer points to. */
