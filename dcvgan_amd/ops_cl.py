@@ -331,29 +331,103 @@ class _ConvCl(Function):
             if into is not None:
                 dx = None
         if ctx.needs_input_grad[1]:
-            need = _fn("wgrad_workspace_bytes")(C.byref(g), C.byref(xd), C.byref(dyd))
-            if need == 0:
-                raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + L.dcv_last_error().decode())
-            wsp, wsn = _ws("clconv", need, x.device)
-            from . import ops as _o
-            tgt = _o.grad_target(w) if _o._OWN_ACCUMULATION else None
-            if tgt is not None:      # a later contribution to this parameter's gradient: added by the slab reduce (ops.grad_target), nothing for autograd to sum
-                check(_fn("conv_backward_weight_acc")(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
-                      "dcv_cl_conv_backward_weight_acc")
-            else:
-                slot = getattr(w, "_dcv_grad_slot", None)       # data parallel: the parameter's slice of its bucket's flat buffer (optim.GradBucket), as on the fp32 path
-                if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _o._Conv._epoch[0] and _o._OWN_ACCUMULATION:
-                    w._dcv_slot_epoch = _o._Conv._epoch[0]
-                    b = getattr(w, "_dcv_bucket", None)
-                    if b is not None and b() is not None:
-                        b().before_slot_write(w)
-                    dw = slot.detach()
-                else:
-                    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
-                check(_fn("conv_backward_weight")(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
-                if _o._OWN_ACCUMULATION:
-                    _o.note_first(w, dw)
+            dw = _wgrad_on_side(g, x, xd, dy, dyd, w)
         return dx, dw, None, None, None, None, None, None, None
+
+
+def _wgrad_on_side(g, x, xd, dy, dyd, w):
+    """The layer's weight gradient: on the chain stream's companion where that is allowed (below), else in place."""
+    need = _fn("wgrad_workspace_bytes")(C.byref(g), C.byref(xd), C.byref(dyd))
+    if need == 0:
+        raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + lib().dcv_last_error().decode())
+    side = _wgrad_side_stream(x.device, w)
+    if side is None:
+        return _wgrad_cl(g, x, xd, dy, dyd, w, need)
+    cur = torch.cuda.current_stream(x.device)
+    side.wait_stream(cur)
+    for t in (x, dy):
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        dw = _wgrad_cl(g, x, xd, dy, dyd, w, need)
+    _wgrad_join_at_end(x.device, cur, side)
+    return dw
+
+
+# Weight gradients off the chain (round 5).  Nothing in a backward pass reads a weight gradient, so it need not sit between a layer's data gradient and the next layer's
+# BatchNorm backward on the same stream: the main stream's backward (the generators' chain, the longest serial one of the iteration) hands its weight gradients to ONE
+# companion stream.  The companion waits for the chain up to the call (x, dy and earlier sums are complete), the chain never waits for the companion, and the engine's
+# end-of-backward callback joins them (optimiser, collective and host reads then see complete gradients).  One companion = one order: the sums into a parameter stay in
+# host order, the results are bit-identical.  The kernels are the same; they now run beside HBM-bound BatchNorm passes and under-filled deep layers instead of between them:
+# surreal-depth1 B = 100, same-box alternating triples on four boxes: 38.7 -> 37.7, 38.7 -> 37.75, 37.95 -> 37.55, 38.25 -> 37.45 ms; isogd-depth 33.25 -> 32.5
+# (profiles/r05_ab_cl16.txt).  Only with the library's own gradient sums (a sum autograd forms would be a kernel on the chain's stream reading the companion's result
+# unordered) and never with data-parallel buckets (their collectives are ordered on the chain's stream).  Measured and not shipped: the discriminator lanes' weight
+# gradients on companions of their own (seven streams on the runtime's four hardware queues: 39.15 ms, slower than none) or on the same companion (box-dependent: -0.15 ms
+# on one, +0.7 on another, one 50 ms iteration average on a third config); the companion's launch before the layer's data gradient instead of after it (38.3).
+# DCV_CL_NO_WGRAD_SIDE=1: in-stream, as before; DCV_CL_WGRAD_SIDE_LANES=1 (+ DCV_CL_WGRAD_SIDE_PER_CHAIN=1): the measured variants (A/B).
+_WGRAD_SIDE = os.environ.get("DCV_CL_NO_WGRAD_SIDE") is None
+_WGRAD_SIDE_LANES = os.environ.get("DCV_CL_WGRAD_SIDE_LANES") is not None
+_WGRAD_SIDE_SHARED = os.environ.get("DCV_CL_WGRAD_SIDE_PER_CHAIN") is None
+_side_streams = {}
+_join_pending = set()
+
+
+def _wgrad_side_stream(device, w):
+    from . import ops as _o
+    # (only with the library's own gradient sums: a sum autograd forms is a kernel on the CHAIN's stream that would read the companion's result unordered;
+    #  a first contribution is handed to autograd, which takes it over without a kernel — it holds the only reference)
+    if not _WGRAD_SIDE or not _o._OWN_ACCUMULATION or not isinstance(w, torch.nn.Parameter) or w._backward_hooks or getattr(w, "_dcv_bucket", None) is not None \
+            or getattr(w, "_dcv_grad_slot", None) is not None:
+        return None
+    cur = torch.cuda.current_stream(device)
+    if not _WGRAD_SIDE_LANES and cur.cuda_stream != torch.cuda.default_stream(device).cuda_stream:
+        return None
+    key = (device.index, 0 if _WGRAD_SIDE_SHARED else cur.cuda_stream)
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device)
+    return s
+
+
+def _wgrad_join_at_end(device, cur, side):
+    """Once per (backward pass, chain stream): when the engine has run the last node, the chain's stream waits for its companion."""
+    key = (device.index, cur.cuda_stream, torch._C._current_graph_task_id())
+    if key in _join_pending:
+        return
+    _join_pending.add(key)
+
+    def join():
+        # (the engine has already joined the leaf streams with the caller's ambient stream when the final callbacks run — under a guard that makes that ambient stream
+        # current — so the caller's stream must wait for the companion itself, not only through the chain's stream)
+        _join_pending.discard(key)
+        cur.wait_stream(side)
+        amb = torch.cuda.current_stream(device)
+        if amb.cuda_stream != cur.cuda_stream:
+            amb.wait_stream(side)
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def _wgrad_cl(g, x, xd, dy, dyd, w, need):
+    """The weight gradient of one CL16 convolution on the CURRENT stream: returns the tensor for autograd, or None when it was added into an existing target."""
+    from . import ops as _o
+    wsp, wsn = _ws("clconv", need, x.device)
+    tgt = _o.grad_target(w) if _o._OWN_ACCUMULATION else None
+    if tgt is not None:      # a later contribution to this parameter's gradient: added by the slab reduce (ops.grad_target), nothing for autograd to sum
+        check(_fn("conv_backward_weight_acc")(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
+              "dcv_cl_conv_backward_weight_acc")
+        return None
+    slot = getattr(w, "_dcv_grad_slot", None)       # data parallel: the parameter's slice of its bucket's flat buffer (optim.GradBucket), as on the fp32 path
+    if slot is not None and w.grad is None and getattr(w, "_dcv_slot_epoch", None) is not _o._Conv._epoch[0] and _o._OWN_ACCUMULATION:
+        w._dcv_slot_epoch = _o._Conv._epoch[0]
+        b = getattr(w, "_dcv_bucket", None)
+        if b is not None and b() is not None:
+            b().before_slot_write(w)
+        dw = slot.detach()
+    else:
+        dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+    check(_fn("conv_backward_weight")(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_cl_conv_backward_weight")
+    if _o._OWN_ACCUMULATION:
+        _o.note_first(w, dw)
+    return dw
 
 
 def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, grad_slot=None, bn_stats=None, act_slot=None):
