@@ -268,7 +268,9 @@ def stress_leg(dev, half, B=100, steps=5):
         gs = [p.grad for m in (vdis, gdis) for p in m.parameters() if p.grad is not None]
         zero, tot = sum(int((g == 0).sum()) for g in gs), sum(g.numel() for g in gs)
         finite = bool(torch.isfinite(yv).all() and torch.isfinite(yg).all() and all(bool(torch.isfinite(g).all()) for g in gs))
-        step()
+        for _ in range(4):      # untimed: the caching allocator reaches its steady state (tensors the weight gradients' companion stream still reads are returned late: the
+            step()              # first steps of a new shape allocate — a device synchronisation each; with one warm-up step the bf16 leg, which runs first, read 68 ms for 52)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
