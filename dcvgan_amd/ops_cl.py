@@ -248,10 +248,19 @@ def _packed(w: torch.Tensor, which: int, g: ConvGeom, xd, yd, key_dims):
         nb = _fn("packed_bytes")(C.byref(g), C.byref(xd), C.byref(yd), which)
         if nb == 0:
             raise N.NativeError("dcv_cl_packed_bytes: " + L.dcv_last_error().decode())
-        e = cache[key] = [None, torch.empty(nb, dtype=torch.uint8, device=w.device)]
+        e = cache[key] = [None, torch.empty(nb, dtype=torch.uint8, device=w.device), None, None]
+    cur = torch.cuda.current_stream(w.device)
     if e[0] != stamp:
+        if e[3] is not None and e[3].cuda_stream != cur.cuda_stream and e[2] is not None:
+            cur.wait_event(e[2])      # (a stream that still reads the old tiles is not waited for: a repack follows an optimiser step, and every consumer of the old weights is ordered before that)
         check(_fn("pack_weights")(C.byref(g), C.byref(xd), C.byref(yd), which, ptr(w), ptr(e[1]), e[1].numel(), stream_ptr()), "dcv_cl_pack_weights")
         e[0] = stamp
+        if e[2] is None:
+            e[2] = torch.cuda.Event()
+        e[2].record(cur)
+        e[3] = cur
+    elif e[3] is not None and e[3].cuda_stream != cur.cuda_stream:
+        cur.wait_event(e[2])          # packed on another stream (a discriminator lane, the D phase's generator stream): this stream's kernels read the tiles behind that launch
     return e[1]
 
 
