@@ -216,6 +216,58 @@ def deliver_small(p, t):
 
 _OWN_ACCUMULATION = os.environ.get("DCV_TORCH_GRAD_ADDS") is None      # DCV_TORCH_GRAD_ADDS=1: leave the sums to autograd (A/B, bit-identity test)
 
+# --------------------------------------------------------------------------- #
+# Weight gradients off the chain (round 5).  Nothing in a backward pass reads a weight gradient, so it need not sit between a layer's data gradient and the next layer's
+# BatchNorm backward on the same stream: the main stream's backward (the generators' chain, the longest serial one of the iteration) hands its weight gradients to ONE
+# companion stream.  The companion waits for the chain up to the call (x, dy and earlier sums are complete), the chain never waits for the companion, and the engine's
+# end-of-backward callback joins them (optimiser, collective and host reads then see complete gradients).  One companion = one order: the sums into a parameter stay in
+# host order, the results are bit-identical.  The kernels are the same; they now run beside HBM-bound BatchNorm passes and under-filled deep layers instead of between them.
+#   bf16 channels-last path, surreal-depth1 B = 100, same-box alternating runs on five boxes: 38.7 -> 37.7, 38.7 -> 37.75, 37.95 -> 37.55, 38.25 -> 37.45, 38.42 -> 37.35 ms;
+#   isogd-depth 33.74 -> 32.66;   fp32 headline (isogd-depth B = 70): 109.63 -> 108.80 ms (profiles/r05_ab_cl16.txt, calls 26-33).
+# Only with the library's own gradient sums (a sum autograd forms would be a kernel on the chain's stream reading the companion's result unordered; a FIRST contribution is
+# handed to autograd, which takes it over without a kernel — it holds the only reference) and never with data-parallel buckets (their collectives are ordered on the
+# chain's stream).  Measured on the 16-bit path and not shipped: the discriminator lanes' weight gradients on companions of their own (seven streams on the runtime's four
+# hardware queues: 39.15 ms, slower than none), on the same companion (box-dependent: -0.15 ms on one, +0.7 on another), in the G phase only (neutral / +0.7); the
+# companion's launch before the layer's data gradient instead of after it (38.3).  (Round 3 tried a LOW-PRIORITY side stream released by a per-layer event on the fp32 path and
+# lost 0.3-1.2 ms; this form — normal priority, stream-wait on the chain, no per-layer join — wins there too.)
+# DCV_NO_WGRAD_SIDE=1: in-stream, as before, on both paths (DCV_CL_NO_WGRAD_SIDE=1: on the 16-bit path only) — A/B.
+# --------------------------------------------------------------------------- #
+_WGRAD_SIDE = os.environ.get("DCV_NO_WGRAD_SIDE") is None
+_side_streams = {}
+_join_pending = set()
+
+
+def wgrad_companion(device, w, enabled: bool = True):
+    """The companion stream for parameter `w`'s weight gradient, or None: in-stream."""
+    if not (_WGRAD_SIDE and enabled and _OWN_ACCUMULATION) or not isinstance(w, torch.nn.Parameter) or w._backward_hooks \
+            or getattr(w, "_dcv_bucket", None) is not None or getattr(w, "_dcv_grad_slot", None) is not None:
+        return None
+    cur = torch.cuda.current_stream(device)
+    if cur.cuda_stream != torch.cuda.default_stream(device).cuda_stream:      # the discriminators' lanes already run beside one another
+        return None
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device)
+    return s
+
+
+def wgrad_join_at_end(device, cur, side) -> None:
+    """Once per (backward pass, chain stream): when the engine has run the last node, the chain's stream — and the caller's — wait for the companion."""
+    key = (device.index, cur.cuda_stream, _task_id())
+    if key in _join_pending:
+        return
+    _join_pending.add(key)
+
+    def join():
+        # (the engine has already joined the leaf streams with the caller's ambient stream when the final callbacks run — under a guard that makes that ambient stream
+        # current — so the caller's stream must wait for the companion itself, not only through the chain's stream)
+        _join_pending.discard(key)
+        cur.wait_stream(side)
+        amb = torch.cuda.current_stream(device)
+        if amb.cuda_stream != cur.cuda_stream:
+            amb.wait_stream(side)
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
 
 class _Conv(Function):
     # identity token of the current backward pass: a weight's gradient slot is handed out once per backward (new_backward_epoch() is called by
@@ -303,7 +355,25 @@ class _Conv(Function):
             _PackCache.commit(pk)
             if into is not None:
                 dx = None
-        if ctx.needs_input_grad[1]:
+        side = wgrad_companion(x.device, w) if ctx.needs_input_grad[1] else None
+        if side is not None:      # the main chain's weight gradient on the companion stream (above)
+            cur = torch.cuda.current_stream(x.device)
+            side.wait_stream(cur)
+            for t in (x, dy):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
+                wsp, wsn = _ws("conv", need, x.device)
+                tgt = grad_target(w)
+                if tgt is not None:
+                    check(L.dcv_conv_backward_weight_acc(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
+                          "dcv_conv_backward_weight_acc")
+                else:
+                    dw = _empty(w.shape, w.device)
+                    check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
+                    note_first(w, dw)
+            wgrad_join_at_end(x.device, cur, side)
+        elif ctx.needs_input_grad[1]:
             # data parallel: the parameter's slice of its bucket's flat gradient buffer (optim.GradBucket) — the first weight gradient of a
             # backward is written straight into it (autograd adopts the returned tensor as .grad); a second use of the same weight in one
             # backward (D on the real and the fake batch) gets a tensor of its own, which autograd adds

@@ -349,7 +349,8 @@ def _wgrad_on_side(g, x, xd, dy, dyd, w):
     need = _fn("wgrad_workspace_bytes")(C.byref(g), C.byref(xd), C.byref(dyd))
     if need == 0:
         raise N.NativeError("dcv_cl_wgrad_workspace_bytes: " + lib().dcv_last_error().decode())
-    side = _wgrad_side_stream(x.device, w)
+    from . import ops as _o
+    side = _o.wgrad_companion(x.device, w, _WGRAD_SIDE)
     if side is None:
         return _wgrad_cl(g, x, xd, dy, dyd, w, need)
     cur = torch.cuda.current_stream(x.device)
@@ -358,61 +359,12 @@ def _wgrad_on_side(g, x, xd, dy, dyd, w):
         t.record_stream(side)
     with torch.cuda.stream(side):
         dw = _wgrad_cl(g, x, xd, dy, dyd, w, need)
-    _wgrad_join_at_end(x.device, cur, side)
+    _o.wgrad_join_at_end(x.device, cur, side)
     return dw
 
 
-# Weight gradients off the chain (round 5).  Nothing in a backward pass reads a weight gradient, so it need not sit between a layer's data gradient and the next layer's
-# BatchNorm backward on the same stream: the main stream's backward (the generators' chain, the longest serial one of the iteration) hands its weight gradients to ONE
-# companion stream.  The companion waits for the chain up to the call (x, dy and earlier sums are complete), the chain never waits for the companion, and the engine's
-# end-of-backward callback joins them (optimiser, collective and host reads then see complete gradients).  One companion = one order: the sums into a parameter stay in
-# host order, the results are bit-identical.  The kernels are the same; they now run beside HBM-bound BatchNorm passes and under-filled deep layers instead of between them:
-# surreal-depth1 B = 100, same-box alternating triples on four boxes: 38.7 -> 37.7, 38.7 -> 37.75, 37.95 -> 37.55, 38.25 -> 37.45 ms; isogd-depth 33.25 -> 32.5
-# (profiles/r05_ab_cl16.txt).  Only with the library's own gradient sums (a sum autograd forms would be a kernel on the chain's stream reading the companion's result
-# unordered) and never with data-parallel buckets (their collectives are ordered on the chain's stream).  Measured and not shipped: the discriminator lanes' weight
-# gradients on companions of their own (seven streams on the runtime's four hardware queues: 39.15 ms, slower than none) or on the same companion (box-dependent: -0.15 ms
-# on one, +0.7 on another, one 50 ms iteration average on a third config); the companion's launch before the layer's data gradient instead of after it (38.3).
-# DCV_CL_NO_WGRAD_SIDE=1: in-stream, as before; DCV_CL_WGRAD_SIDE_LANES=1 (+ DCV_CL_WGRAD_SIDE_PER_CHAIN=1): the measured variants (A/B).
-_WGRAD_SIDE = os.environ.get("DCV_CL_NO_WGRAD_SIDE") is None
-_WGRAD_SIDE_LANES = os.environ.get("DCV_CL_WGRAD_SIDE_LANES") is not None
-_WGRAD_SIDE_SHARED = os.environ.get("DCV_CL_WGRAD_SIDE_PER_CHAIN") is None
-_side_streams = {}
-_join_pending = set()
-
-
-def _wgrad_side_stream(device, w):
-    from . import ops as _o
-    # (only with the library's own gradient sums: a sum autograd forms is a kernel on the CHAIN's stream that would read the companion's result unordered;
-    #  a first contribution is handed to autograd, which takes it over without a kernel — it holds the only reference)
-    if not _WGRAD_SIDE or not _o._OWN_ACCUMULATION or not isinstance(w, torch.nn.Parameter) or w._backward_hooks or getattr(w, "_dcv_bucket", None) is not None \
-            or getattr(w, "_dcv_grad_slot", None) is not None:
-        return None
-    cur = torch.cuda.current_stream(device)
-    if not _WGRAD_SIDE_LANES and cur.cuda_stream != torch.cuda.default_stream(device).cuda_stream:
-        return None
-    key = (device.index, 0 if _WGRAD_SIDE_SHARED else cur.cuda_stream)
-    s = _side_streams.get(key)
-    if s is None:
-        s = _side_streams[key] = torch.cuda.Stream(device)
-    return s
-
-
-def _wgrad_join_at_end(device, cur, side):
-    """Once per (backward pass, chain stream): when the engine has run the last node, the chain's stream waits for its companion."""
-    key = (device.index, cur.cuda_stream, torch._C._current_graph_task_id())
-    if key in _join_pending:
-        return
-    _join_pending.add(key)
-
-    def join():
-        # (the engine has already joined the leaf streams with the caller's ambient stream when the final callbacks run — under a guard that makes that ambient stream
-        # current — so the caller's stream must wait for the companion itself, not only through the chain's stream)
-        _join_pending.discard(key)
-        cur.wait_stream(side)
-        amb = torch.cuda.current_stream(device)
-        if amb.cuda_stream != cur.cuda_stream:
-            amb.wait_stream(side)
-    torch.autograd.Variable._execution_engine.queue_callback(join)
+# Weight gradients off the chain: ops.wgrad_companion (the main stream's backward hands them to one companion stream; same kernels, bit-identical results).
+_WGRAD_SIDE = os.environ.get("DCV_CL_NO_WGRAD_SIDE") is None      # (DCV_NO_WGRAD_SIDE=1 turns it off on both paths)
 
 
 def _wgrad_cl(g, x, xd, dy, dyd, w, need):

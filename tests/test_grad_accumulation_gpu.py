@@ -8,6 +8,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
 
 
 def _run(cfg_name, B, own, cl=False, steps=2):
@@ -35,6 +36,42 @@ def _run(cfg_name, B, own, cl=False, steps=2):
     finally:
         ops._OWN_ACCUMULATION = old
         ops_cl.enable(False)
+
+
+def _run_schedule(name, B, companion, cl):
+    from dcvgan_amd import native, ops, ops_cl, trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    native.lib()
+    old = (ops._WGRAD_SIDE, ops_cl._WGRAD_SIDE)
+    ops._WGRAD_SIDE = companion
+    ops_cl.enable(cl)
+    try:
+        cfg = CONFIGS[name].scaled(batchsize=B, width_div=2)
+        torch.manual_seed(5)
+        models = trainer.build_models(cfg, DEV)
+        r = PhiloxRng(17)
+        for m in models.values():
+            m._rng = r
+        runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=True)
+        g = torch.Generator().manual_seed(6)
+        xc = (torch.rand(B, 3, 16, 64, 64, generator=g) * 2 - 1).to(DEV); xg = (torch.rand(B, cfg.channel, 16, 64, 64, generator=g) * 2 - 1).to(DEV)
+        outs = [runner.step(xc, xg, t) for t in (2, 9, 5)]
+        return outs, torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).clone()
+    finally:
+        ops_cl.enable(False)
+        ops._WGRAD_SIDE, ops_cl._WGRAD_SIDE = old
+
+
+@pytest.mark.parametrize("name,cl", [("isogd-depth", False), ("surreal-depth1", False), ("isogd-flow", True)])
+def test_weight_gradients_on_the_companion_stream_change_no_bit(name, cl):
+    """ops.wgrad_companion: the main chain's weight gradients run on a companion stream, joined by the autograd engine's end-of-backward callback.  Same kernels, same order
+    of the sums into every parameter: three iterations (one of them without a generator update for surreal-depth1) give the losses and parameters of the in-stream
+    schedule, bit for bit — on the fp32 path and on the 16-bit one."""
+    la, pa = _run_schedule(name, 3, True, cl)
+    lb, pb = _run_schedule(name, 3, False, cl)
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb)
 
 
 @pytest.mark.parametrize("name,cl", [("isogd-depth", False), ("surreal-depth1", False), ("isogd-depth", True)])
