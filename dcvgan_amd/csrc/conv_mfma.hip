@@ -1455,6 +1455,118 @@ __global__ __launch_bounds__(256) void widen_rows_kernel(const GatherArgs a) {
 }
 
 // --------------------------------------------------------------------------- //
+// widen_mfma_kernel (round 6): the same op on the matrix pipe.  widen_rows_kernel<3> spends 27 VALU multiply-adds plus a broadcast LDS read per 4 of
+// them on every output element and ran the RGB head's data gradient at 3.5 TB/s of stores (0.68 ms for 2.35 GB).  As a GEMM the op is
+// [OC x K] x [K x positions] with K = 9 RC (27, padded to 28): 14 v_mfma_f32_32x32x2_f32 per 32 channels x 32 positions, a quarter of the store time at the
+// HBM rate, so the kernel is bound by its stores.  One wave owns one output row: the A fragments (the packed weights of ALL 32 MT channels: 14 MT registers)
+// are staged in LDS once per workgroup; per half row the wave loads its 14 B values straight from the gathered tensor (lane = column, lane half = k parity; rows
+// outside the image and the two halo columns arrive as zeros through the out-of-range buffer offset; the tensor is 3 channels: every load is an L1/L2 hit),
+// runs 14 MFMAs per channel tile and stores its 16 registers, each one 128-byte run of a channel row per lane half.  k order = (rc, row tap, column tap) ascending, the
+// order widen_rows_kernel's fma chain uses: results are bit-identical to it.
+// --------------------------------------------------------------------------- //
+template <int RC, int MT>
+__global__ __launch_bounds__(256, 4) void widen_mfma_kernel(const GatherArgs a, int groups) {
+    constexpr int K = RC * 9, KS = (K + 1) / 2;
+    __shared__ float wl[2 * KS][MT * 32];              // weights in natural k order (rc, row tap, column tap); the padding row is zero
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int e = tid; e < 2 * KS * MT * 32; e += 256) {
+        const int k = e / (MT * 32), oc = e - k * (MT * 32);
+        const int rc = k / 9, t = k - rc * 9;
+        int pt = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pt = (t == q) ? a.s_local[q] : pt;
+        wl[k][oc] = (k < K && oc < a.OCp) ? a.wp[(int64_t)(rc * 9 + pt) * a.OCp + oc] : 0.f;
+    }
+    const uint32_t gpp = ((uint32_t)a.OH >> 2) / (uint32_t)groups;      // workgroups per plane
+    uint32_t plane, gb;
+    xcd_plane_map(blockIdx.x, gpp, gridDim.x, plane, gb);
+    const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
+    // this lane's k of MFMA step m is 2 m + lhi
+    int32_t kb4[KS];        // byte offset of that k inside the gathered tensor, relative to (first tap row, column - 1)
+    // per MFMA step (bit m): the lane's k is padding / has column tap 0 / column tap 2 / row tap 0, 1, 2
+    uint32_t padmask = 0, b0mask = 0, b2mask = 0, r0mask = 0, r1mask = 0, r2mask = 0;
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+        const int k = 2 * m + lhi;
+        const bool live = k < K;
+        const int kk = live ? k : 0;
+        const int rc = kk / 9, t = kk - rc * 9, ra = t / 3, b = t - ra * 3;
+        kb4[m] = rc * a.s_stepA + 4 * (ra * a.x_sh + b);
+        padmask |= live ? 0u : 1u << m;
+        b0mask |= (live && b == 0) ? 1u << m : 0u;
+        b2mask |= (live && b == 2) ? 1u << m : 0u;
+        r0mask |= (live && ra == 0) ? 1u << m : 0u;
+        r1mask |= (live && ra == 1) ? 1u << m : 0u;
+        r2mask |= (live && ra == 2) ? 1u << m : 0u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base + a.td.delta[0]) * a.x_sd), 0, 0x80000000u, 0x00020000);
+    const int OC = a.OC, act = a.act, accumulate = a.accumulate;
+    const float slope = a.slope;
+    // (run_gather has checked that a sample's output spans < 2^29 elements and OCp channel strides < 2^30)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd, 0, 0x80000000u, 0x00020000);
+    const int ysh = (int)a.y_sh, ysw = (int)a.y_sw;
+    const uint32_t ysc4 = (uint32_t)a.y_sc * 4u;
+    const bool full = OC == MT * 32;
+
+    auto load_b = [&](int oh, int x0, float (&bv)[KS]) {
+        // rows oh + p_ihmin + ra (validity is wave-uniform), columns x0 + l31 + b - 1 (only the image's first and last column have a halo tap)
+        const int ih0 = oh + a.p_ihmin;
+        const int col = x0 + l31;
+        uint32_t bad = padmask | (col == 0 ? b0mask : 0u) | (col == a.tw.size - 1 ? b2mask : 0u);
+        if ((unsigned)ih0 >= (unsigned)a.th.size) bad |= r0mask;
+        if ((unsigned)(ih0 + 1) >= (unsigned)a.th.size) bad |= r1mask;
+        if ((unsigned)(ih0 + 2) >= (unsigned)a.th.size) bad |= r2mask;
+        const int base4 = 4 * (ih0 * a.x_sh + col - 1);
+#pragma unroll
+        for (int m = 0; m < KS; ++m) {
+            const uint32_t vo = ((bad >> m) & 1u) ? 0x80000000u : (uint32_t)(base4 + kb4[m]);
+            bv[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, 0, 0));
+        }
+    };
+
+    const int ntile = groups * 2;              // (row, half row) pairs of this wave
+    __syncthreads();
+    // Channel tile outermost, the wave's `groups` CONSECUTIVE rows inside: a channel-row run of groups x 256 bytes is written back to back by one wave and the
+    // four waves' runs adjoin, instead of 128 bytes per channel and tile (measured, B = 70: 0.66 -> 0.57 ms); non-temporal stores (nothing reads the tile
+    // back through this L2): 0.57 -> 0.53 ms.  B is re-read per channel tile (L1 hits: the workgroup's 3 x 18 gathered rows are 14 KB).
+    const int ohw = (int)gb * groups * 4 + wave * groups;
+#pragma unroll 1
+    for (int mt = 0; mt < MT; ++mt) {
+        float af[KS];
+#pragma unroll
+        for (int m = 0; m < KS; ++m) af[m] = wl[2 * m + lhi][mt * 32 + l31];
+        float bcur[KS], bnxt[KS];
+        load_b(ohw, 0, bcur);
+#pragma unroll 1
+        for (int tt = 0; tt < ntile; ++tt) {
+            const int oh = ohw + (tt >> 1), x0 = (tt & 1) * 32;
+            if (tt + 1 < ntile) load_b(ohw + ((tt + 1) >> 1), ((tt + 1) & 1) * 32, bnxt);
+            // stores: one 32-bit offset per lane and tile, the channel of (mt, r) as the scalar offset (no per-register 64-bit addresses to keep alive)
+            const uint32_t yv = (uint32_t)(4 * (oh * ysh + (x0 + l31) * ysw)) + (uint32_t)(4 * lhi) * ysc4;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bcur[m], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ocb = mt * 32 + (r & 3) + 8 * (r >> 2);
+                const uint32_t vo = (full || ocb + 4 * lhi < OC) ? yv : 0x80000000u;
+                const uint32_t so = (uint32_t)ocb * ysc4;
+                float v = acc[r];
+                if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, vo, so, 0));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, apply_act(v, act, slope)), yrs, vo, so, 2);   // aux 2 = nt
+            }
+#pragma unroll
+            for (int m = 0; m < KS; ++m) bcur[m] = bnxt[m];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- //
 // thin_quad_kernel: OC <= 4 outputs of a 4x4, stride-2, pad-1 SCATTER-form op (conv data gradient / transposed-conv forward)
 // on 32-wide gathered rows -> 64-wide output rows, 1 or 4 depth taps (stride 1, no depth padding): the geometry generator's
 // depth / flow head and the data gradients of the 3-D discriminators' stems.  thin_rows_kernel runs these as four stride-parity
@@ -2294,6 +2406,109 @@ __global__ __launch_bounds__(256) void thin_wgrad3_kernel(const ThinWgradArgs a)
 // (independent loads, 4-way unrolled) and wave 0 combines the four partial sums in a fixed order:
 // bitwise reproducible, and 16x more loads in flight than one thread walking all S splits.
 // J % 4 == 0 (every 4x4-tap layer): four consecutive j per lane, 16-byte loads — the same order of additions per element
+// --------------------------------------------------------------------------- //
+// thinj_wgrad_kernel (round 6): the weight gradient of a 3x3 / stride-1 / pad-1 layer with at most 3 GATHERED channels and 128 k dense ones on 64-wide
+// rows — the colour generator's RGB head, R[dc][gc][kh][kw] = sum D[n, dc, r, c] G[n, gc, r - 1 + kh, c - 1 + kw] with D the head's 2.35 GB input.  The
+// generic tile (128 x 32, one LDS buffer, two barriers per 32 positions) ran it at 0.61 ms = 3.9 TB/s; the op is J = 9 GC <= 32 wide, so one 32x32 MFMA
+// column covers it and the kernel only has to stream D once.  A wave owns 32 dense channels and ONE accumulator tile for its whole life; its A operand is
+// read straight from HBM, 16 bytes per lane: lane (channel i, half h) holds columns 8q + 4h .. + 3 of a row, and MFMA (q, e) reduces over columns
+// 8q + e (half 0) and 8q + 4 + e (half 1) — any pairing of positions is a valid K order as long as B follows it.  B (the gathered taps of the same two
+// columns, lane = (gc, kh, kw)) comes from the chunk's G rows staged in LDS ([row][gc][x + 1], pitch 67: the 27 tap addresses of a half wave fall
+// on 27 different banks).  The four waves of a workgroup share the position chunk and the staged rows; a workgroup walks `cpw` chunks and writes one slab.
+// --------------------------------------------------------------------------- //
+struct ThinJArgs {
+    const float* d;
+    const float* g;
+    float* slab;
+    int32_t OH, DC, GC, J, rpc, nchunk, cpw, cpi;   // rows per chunk, chunks, chunks per workgroup, chunks per image
+    int64_t d_sn, g_sn;
+    int32_t d_sc, d_sh, g_sc, g_sh;
+};
+
+template <int GC>
+__global__ __launch_bounds__(256, 3) void thinj_wgrad_kernel(const ThinJArgs a) {
+    constexpr int PITCH = 67, RMAX = 8 + 2;
+    __shared__ float gs[2][RMAX * GC][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int rpc = a.rpc, nrow = (rpc + 2) * GC;
+    for (int e = tid; e < 2 * RMAX * GC * PITCH; e += 256) (&gs[0][0][0])[e] = 0.f;   // halo columns (and everything a lane past J may read) are zero for good
+    const int c0 = blockIdx.x * a.cpw, c1 = min(a.nchunk, c0 + a.cpw);
+    const int ch = blockIdx.y * 128 + wave * 32 + l31;                                  // this lane's dense channel
+    const uint32_t dvo = ch < a.DC ? (uint32_t)(4 * (ch * a.d_sc + 4 * lhi)) : 0x80000000u;
+    // this lane's tap: j = (gc, kh, kw); lanes past J read tap 0 (their columns are not stored)
+    const int j = l31 < a.J ? l31 : 0;
+    const int jgc = j / 9, jt = j - jgc * 9, jkh = jt / 3, jkw = jt - jkh * 3;
+    const int jbase = (jkh * GC + jgc) * PITCH + jkw + 4 * lhi;                           // word offset of column 0 of chunk row 0 for this lane's tap
+    // staging: element e of a chunk's G rows = (row rr of nrow, column x): thread t takes e = t, t + 256, ..
+    constexpr int SPT = (RMAX * GC * 64 + 255) / 256;
+    float sv[SPT];
+    auto stage_load = [&](int c) {
+        const int n = c / a.cpi, y0 = (c - n * a.cpi) * rpc;
+        const float* __restrict__ gb = a.g + (int64_t)n * a.g_sn;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int e = tid + 256 * i, rr = e >> 6, x = e & 63;
+            const int yl = rr / GC, gc = rr - yl * GC, y = y0 - 1 + yl;
+            sv[i] = (rr < nrow && (unsigned)y < (unsigned)a.OH) ? gb[(int64_t)gc * a.g_sc + (int64_t)y * a.g_sh + x] : 0.f;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const int e = tid + 256 * i, rr = e >> 6, x = e & 63;
+            if (rr < nrow) gs[buf][rr][x + 1] = sv[i];
+        }
+    };
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 av[2][8];
+    auto load_a = [&](int c, int rl, f32x4 (&dst)[8]) {
+        const int n = c / a.cpi, y = (c - n * a.cpi) * rpc + rl;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d + (int64_t)n * a.d_sn + (int64_t)y * a.d_sh), 0, 0x80000000u, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, dvo, 32 * q, 0));
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();
+    if (c0 < c1) {
+        stage_load(c0);
+        stage_store(0);
+        load_a(c0, 0, av[0]);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int c = c0; c < c1; ++c, buf ^= 1) {
+        if (c + 1 < c1) stage_load(c + 1);
+        for (int rl = 0; rl < rpc; rl += 2) {
+            // two rows per trip so the A double buffer is indexed statically
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = rl + u;
+                if (r >= rpc) break;
+                // next row's A (the next chunk's first row at the end of this one)
+                if (r + 1 < rpc) load_a(c, r + 1, av[u ^ 1]);
+                else if (c + 1 < c1) load_a(c + 1, 0, av[u ^ 1]);
+                const float* __restrict__ brow = &gs[buf][0][0] + jbase + r * (GC * PITCH);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q][e], brow[8 * q + e], acc, 0, 0, 0);
+            }
+        }
+        if (c + 1 < c1) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+    float* __restrict__ out = a.slab + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 128 * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dcl = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        out[dcl * 32 + l31] = l31 < a.J ? acc[r] : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int DC, int J, int DCp, int Jp, int acc) {
     __shared__ float4 part[3][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -2364,13 +2579,13 @@ static std::map<std::string, DevTable> g_tables;   // keys start with the device
 
 // A/B switches for tools/ (variant off when the variable is set); read once, not per call
 struct Toggles {
-    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_wgrad_dma, no_wgrad_dma64, no_quad, no_thin_wgrad;
+    bool no_lds_dma, no_dstep, no_patch, no_row64, no_widen, no_widen_mfma, no_thinj_wgrad, no_wgrad_dma, no_wgrad_dma64, no_quad, no_thin_wgrad;
     int half_m;
     bool no_ragged, no_wgrad_d16;
     Toggles() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         no_lds_dma = on("DCV_NO_LDS_DMA"); no_dstep = on("DCV_NO_DSTEP"); no_patch = on("DCV_NO_PATCH"); no_row64 = on("DCV_NO_ROW64");
-        no_widen = on("DCV_NO_WIDEN"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD"); no_thin_wgrad = on("DCV_NO_THIN_WGRAD");
+        no_widen = on("DCV_NO_WIDEN"); no_widen_mfma = on("DCV_NO_WIDEN_MFMA"); no_thinj_wgrad = on("DCV_NO_THINJ_WGRAD"); no_wgrad_dma = on("DCV_NO_WGRAD_DMA"); no_wgrad_dma64 = on("DCV_NO_WGRAD_DMA64"); no_quad = on("DCV_NO_QUAD"); no_thin_wgrad = on("DCV_NO_THIN_WGRAD");
         half_m = getenv("DCV_HALF_M") ? atoi(getenv("DCV_HALF_M")) : -1;
         no_ragged = on("DCV_NO_RAGGED");
         no_wgrad_d16 = on("DCV_NO_WGRAD_D16");
@@ -3027,6 +3242,17 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                     npack = 0;
                     packmax = 0;
                 }
+                // 3 gathered channels (the RGB head's data gradient): K = 27 on the matrix pipe, bound by its stores (widen_mfma_kernel)
+                if (RC == 3 && (OCp == 128 || OCp == 64) && !toggles().no_widen_mfma && xd.sc * 4 * RC < (1ll << 30)) {
+                    const int OHc = c.o_ext[1];
+                    const int groups = OHc % 16 == 0 ? 4 : OHc % 8 == 0 ? 2 : 1;   // rows per wave (measured 1 / 2 / 4 / 8 / 16 at B = 70: 0.57 / 0.53 / 0.53 / 0.70 / 0.80 ms)
+                    const dim3 gm((unsigned)(M64 / 256 / groups));
+                    DCV_NOTE_KERNEL("widen_mfma_kernel<%d, %d>", RC, OCp / 32);
+                    if (OCp == 128) hipLaunchKernelGGL((widen_mfma_kernel<3, 4>), gm, dim3(256), 0, stream, a, groups);
+                    else hipLaunchKernelGGL((widen_mfma_kernel<3, 2>), gm, dim3(256), 0, stream, a, groups);
+                    DCV_LAUNCH_CHECK();
+                    continue;
+                }
                 const dim3 gw((unsigned)(M64 / 256));
                 const size_t shm = (size_t)RC * 9 * OCp * sizeof(float);
                 DCV_NOTE_KERNEL("widen_rows_kernel<%d>", RC);
@@ -3270,6 +3496,50 @@ static int try_thin_wgrad(const float* D, const dcv_dims5& dd, const float* G, c
     return DCV_OK;
 }
 
+// Thin-J weight gradient on the matrix pipe (thinj_wgrad_kernel).  Returns -1 when the geometry is not its own.
+static int try_thinj_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R, const int k[3], const int s[3], const int p[3],
+                           void* ws, size_t ws_bytes, hipStream_t stream, const char* tag, size_t* need_only) {
+    if (toggles().no_thinj_wgrad || eff_precision() == 1) return -1;
+    const int DC = dd.c, GC = gd.c;
+    if (GC != 3 || DC % 128 != 0 || dd.sw != 1 || gd.sw != 1 || dd.n != gd.n) return -1;
+    if (!(k[0] == 1 && k[1] == 3 && k[2] == 3 && s[0] == 1 && s[1] == 1 && s[2] == 1 && p[0] == 0 && p[1] == 1 && p[2] == 1 && dd.d == 1 && gd.d == 1 &&
+          dd.w == 64 && gd.w == 64 && dd.h == gd.h && dd.h % 2 == 0))
+        return -1;
+    // 16-byte loads of the dense operand; 32-bit byte offsets inside one image
+    if (dd.sc % 4 != 0 || dd.sh % 4 != 0 || dd.sn % 4 != 0 || (D && (reinterpret_cast<uintptr_t>(D) & 15) != 0) || dd.sc < 0 || dd.sh < 0 ||
+        (int64_t)DC * dd.sc * 4 + (int64_t)dd.h * dd.sh * 4 >= (1ll << 31) || gd.sc > INT32_MAX / 8 || gd.sh > INT32_MAX / 8 || gd.sc < 0 || gd.sh < 0)
+        return -1;
+    const int OH = dd.h, rpc = OH % 8 == 0 ? 8 : OH % 4 == 0 ? 4 : 2;
+    const int cpi = OH / rpc;
+    const int64_t nchunk64 = (int64_t)dd.n * cpi;
+    if (nchunk64 >= (1 << 30)) return -1;
+    const int nchunk = (int)nchunk64, dtiles = DC / 128;
+    const int target = std::max(1, 768 / dtiles);                  // three workgroups per CU (the kernel's register budget) in one round
+    const int cpw = (nchunk + target - 1) / target;
+    const int S = (nchunk + cpw - 1) / cpw;
+    const size_t need = align_up((size_t)S * DC * 32 * sizeof(float), 256);
+    if (need_only) {
+        *need_only = need + 256;
+        return DCV_OK;
+    }
+    if (!D || !G || !R || !ws) return fail(DCV_EINVAL, "%s: null pointer", tag);
+    if (need > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, need, ws_bytes);
+    ThinJArgs a;
+    memset(&a, 0, sizeof(a));
+    a.d = D; a.g = G; a.slab = static_cast<float*>(ws);
+    a.OH = OH; a.DC = DC; a.GC = GC; a.J = GC * 9; a.rpc = rpc; a.nchunk = nchunk; a.cpw = cpw; a.cpi = cpi;
+    a.d_sn = dd.sn; a.g_sn = gd.sn;
+    a.d_sc = (int32_t)dd.sc; a.d_sh = (int32_t)dd.sh; a.g_sc = (int32_t)gd.sc; a.g_sh = (int32_t)gd.sh;
+    hipLaunchKernelGGL((thinj_wgrad_kernel<3>), dim3((unsigned)S, (unsigned)dtiles), dim3(256), 0, stream, a);
+    DCV_NOTE_KERNEL("thinj_wgrad_kernel<%d> (%d slabs)", GC, S);
+    DCV_LAUNCH_CHECK();
+    const int J = GC * 9;
+    const int64_t tot = (int64_t)DC * J;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, a.slab, R, S, DC, J, DC, 32, t_wgrad_acc);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R,
                      const int k[3], const int s[3], const int p[3], void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
                      size_t* need_only) {
@@ -3281,6 +3551,12 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     {   // the colour generator's stem: VALU kernel
         const int rc_ = try_thin_wgrad(D, dd, G, gd, R, k, s, p, ws, ws_bytes, stream, tag, need_only ? &thin_need : nullptr);
         if (rc_ != -1 && !need_only) return rc_;
+    }
+    {   // the colour generator's RGB head: one MFMA column of taps, the dense operand streamed once
+        size_t tj_need = 0;
+        const int rc_ = try_thinj_wgrad(D, dd, G, gd, R, k, s, p, ws, ws_bytes, stream, tag, need_only ? &tj_need : nullptr);
+        if (rc_ != -1 && !need_only) return rc_;
+        thin_need = std::max(thin_need, tj_need);
     }
     const int J = (int)J64;
     const WgradTile tc = pick_wgrad_tile(DC, J);

@@ -242,6 +242,13 @@ def wgrad_companion(device, w, enabled: bool = True):
     if not (_WGRAD_SIDE and enabled and _OWN_ACCUMULATION) or not isinstance(w, torch.nn.Parameter) or w._backward_hooks \
             or getattr(w, "_dcv_bucket", None) is not None or getattr(w, "_dcv_grad_slot", None) is not None:
         return None
+    # The companion's result may only meet autograd where AccumulateGrad ADOPTS it without a kernel of its own (a kernel or hook on the chain's stream would read the
+    # companion's data unordered): not under create_graph (it clones), not with post-accumulate hooks, not beside a .grad the in-place sum refuses (autograd would add).
+    if torch.is_grad_enabled() or getattr(w, "_post_accumulate_grad_hooks", None):
+        return None
+    g = w.grad
+    if g is not None and not (g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == w.shape):
+        return None
     cur = torch.cuda.current_stream(device)
     if cur.cuda_stream != torch.cuda.default_stream(device).cuda_stream:      # the discriminators' lanes already run beside one another
         return None
@@ -256,6 +263,8 @@ def wgrad_join_at_end(device, cur, side) -> None:
     key = (device.index, cur.cuda_stream, _task_id())
     if key in _join_pending:
         return
+    for k in [k for k in _join_pending if k[2] != key[2]]:      # a backward that raised never ran its callback: its keys go when the next pass registers
+        _join_pending.discard(k)
     _join_pending.add(key)
 
     def join():

@@ -129,8 +129,12 @@ _TWINS = os.environ.get("DCV_CL_NO_TWINS") is None
 
 
 def twin_of(x: torch.Tensor):
+    """x's CL16 source, or None — also when x was written in place since the twin was attached (`clamp_`, `mul_`, a masked write between generator and
+    discriminator): the twin then no longer holds x's values, so the consumer converts x itself and the gradient flows through the modification."""
     t = getattr(x, "_dcv_cl_twin", None) if _TWINS else None
-    return t if (t is not None and t.dtype == _HALF[0] and tuple(t.shape) == tuple(x.shape)) else None
+    if t is None or t.dtype != _HALF[0] or tuple(t.shape) != tuple(x.shape):
+        return None
+    return t if getattr(x, "_dcv_cl_twin_ver", None) == (x._version, x.data_ptr()) else None
 
 
 def carry_twin(dst: torch.Tensor, src: torch.Tensor, view) -> torch.Tensor:
@@ -140,6 +144,7 @@ def carry_twin(dst: torch.Tensor, src: torch.Tensor, view) -> torch.Tensor:
         v = view(t)
         if v.data_ptr() == t.data_ptr() and (v.shape[1] == 1 or v.stride(1) == 1):      # still a channels-last view of the same memory (torch made no copy)
             dst._dcv_cl_twin = v
+            dst._dcv_cl_twin_ver = (dst._version, dst.data_ptr())      # a view shares its base's version counter
     return dst
 
 
@@ -176,6 +181,7 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     y = _ToF32.apply(x)
     if _TWINS:
         y._dcv_cl_twin = x
+        y._dcv_cl_twin_ver = (y._version, y.data_ptr())
     return y
 
 

@@ -419,6 +419,45 @@ def test_iteration_cl16_schedules_and_boundary_shortcuts_change_no_bit(mode):
         assert torch.equal(base[1], other[1])
 
 
+def test_twin_is_dropped_when_the_fp32_tensor_is_modified_in_place():
+    """to_f32() remembers its CL16 source and from_f32() hands that back instead of converting.  If the fp32 tensor was written in place in between
+    (`videos.mul_(0.5)` between generator and discriminator) the source no longer holds its values: the twin must be dropped — forward AND the gradient equal
+    the always-convert route (DCV_CL_NO_TWINS) bit for bit."""
+    from dcvgan_amd import native, ops_cl
+    native.lib()
+    saved = ops_cl._TWINS
+    ops_cl.enable(True)
+    try:
+        g = torch.Generator().manual_seed(5)
+        src32 = torch.randn(2, 8, 4, 16, 16, generator=g).to(DEV)
+        got = {}
+        for twins in (True, False):
+            ops_cl._TWINS = twins
+            leaf = src32.clone().requires_grad_(True)
+            x16 = ops_cl.from_f32(leaf)
+            y = ops_cl.to_f32(x16)
+            if twins:
+                assert ops_cl.twin_of(y) is x16
+            v = y.permute(0, 2, 1, 3, 4)                      # a boundary view, as the generators make
+            v = ops_cl.carry_twin(v, y, lambda t: t.permute(0, 2, 1, 3, 4))
+            y.mul_(0.5)                                       # in place, through the base of the view
+            assert ops_cl.twin_of(y) is None and ops_cl.twin_of(v) is None
+            z16 = ops_cl.from_f32(y)
+            assert z16 is not x16
+            z = ops_cl.to_f32(z16)
+            (gx,) = torch.autograd.grad((z * z).sum(), leaf)
+            got[twins] = (z.detach().clone(), gx.clone())
+        assert torch.equal(got[True][0], got[False][0]) and torch.equal(got[True][1], got[False][1])
+        assert torch.equal(got[True][0], (r16(r16(src32) * 0.5)))   # the modification is in the values the consumer saw
+        # and an untouched tensor keeps the short cut
+        ops_cl._TWINS = True
+        x16 = ops_cl.from_f32(src32)
+        assert ops_cl.from_f32(ops_cl.to_f32(x16)) is x16
+    finally:
+        ops_cl._TWINS = saved
+        ops_cl.enable(False)
+
+
 @pytest.mark.parametrize("case", [("conv2d_64_128", False, 2, 64, 128, 4, 2, 1, (16, 16), 5), ("convT2d_128_64", True, 2, 128, 64, 4, 2, 1, (16, 16), 3), ("convT2d_64_96_w8_n5", True, 2, 64, 96, 4, 2, 1, (8, 8), 5),
                                   ("conv3d_64_128", False, 3, 64, 128, 4, (1, 2, 2), (0, 1, 1), (7, 16, 16), 2), ("conv2d_thin3_32", False, 2, 3, 32, 4, 2, 1, (64, 64), 2),
                                   ("convT2d_latent_50_128", True, 2, 50, 128, 4, 1, 0, (1, 1), 9)], ids=lambda c: c[0])

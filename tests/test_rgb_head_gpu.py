@@ -1,0 +1,122 @@
+"""GPU: the colour generator's RGB head (`Outconv`, /root/reference/src/generator.py:256-282: ConvTranspose2d(2 ngf, 3, 3, 1, 1) + Tanh on 64 x 64 frames)
+on its round-6 kernels — the data gradient as a K = 27 GEMM on the matrix pipe (widen_mfma_kernel) and the weight gradient as one MFMA column of taps
+with the 128-channel operand streamed once (thinj_wgrad_kernel) — against torch on the host, through the C ABI, inside NaN guard bands, on the shapes
+that exercise every index path: image heights that give 4 / 2 / 1 row groups per workgroup, the first and last rows and columns (halo taps), image
+counts that leave XCD slots and the last workgroup ragged, a destination that is a channel slice of a wider buffer (accumulate), 64 and 128 channels,
+and 256 channels for the weight gradient's second channel tile.  The B = 70 shape itself is in tests/test_b70_gpu.py (`cgen.out`)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+GUARD = 8192
+
+
+def rel(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def guarded(t):
+    big = torch.full((t.numel() + 2 * GUARD,), float("nan"), device=t.device, dtype=t.dtype)
+    big[GUARD:GUARD + t.numel()] = t.reshape(-1)
+    return torch.as_strided(big, t.shape, t.stride(), GUARD), big
+
+
+def margins_intact(big, n):
+    return bool(torch.isnan(big[:GUARD]).all() and torch.isnan(big[GUARD + n:]).all())
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from dcvgan_amd import native
+    native.lib()
+    return torch.device("cuda:0")
+
+
+def last_kernel():
+    from dcvgan_amd import native as N
+    L = N.lib()
+    L.dcv_debug_last_kernel.restype = C.c_char_p
+    return L.dcv_debug_last_kernel().decode()
+
+
+# frames, channels into the head, image height (the width is 64: the kernels' row form)
+HEAD_CASES = [(5, 128, 64), (9, 128, 32), (3, 128, 24), (2, 128, 20), (17, 64, 16), (1, 128, 4), (2, 256, 8)]
+
+
+@pytest.mark.parametrize("n,cin,h", HEAD_CASES, ids=lambda v: str(v))
+def test_rgb_head_forward_and_gradients(dev, n, cin, h):
+    from dcvgan_amd import ops
+    g = torch.Generator().manual_seed(100 + n + cin + h)
+    x = torch.randn(n, cin, h, 64, generator=g, requires_grad=True)
+    w = (torch.randn(cin, 3, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    y_ref = torch.tanh(F.conv_transpose2d(x, w, None, 1, 1))
+    cot = torch.randn(y_ref.shape, generator=g)
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * cot).sum(), [x, w])
+    xd, xbig = guarded(x.detach().to(dev)); xd.requires_grad_(True)
+    wd, wbig = guarded(w.detach().to(dev)); wd.requires_grad_(True)
+    y = ops.conv(xd, wd, ops.conv_geom(wd, (1, 1), (1, 1), True), ops.ACT_TANH)
+    cotd, cbig = guarded(cot.to(dev))
+    # (which kernels ran is asserted in the direct C-ABI tests below: the note dcv_debug_last_kernel reads is per thread, and backward runs on autograd's)
+    gx, gw = torch.autograd.grad((y * cotd).sum(), [xd, wd])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(gx).all() and torch.isfinite(gw).all())
+    assert margins_intact(xbig, x.numel()) and margins_intact(wbig, w.numel()) and margins_intact(cbig, cot.numel())
+    assert rel(y, y_ref) < 1e-5
+    assert rel(gx, gx_ref) < 1e-5
+    assert rel(gw, gw_ref) < 2e-5
+    # the first / last rows and columns separately (halo taps): a wrong zero there moves the norm by little
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), h - 1), (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), 63)):
+        assert rel(gx[sl], gx_ref[sl]) < 1e-5
+
+
+@pytest.mark.parametrize("n,cin,h", [(3, 128, 32), (5, 64, 8)], ids=lambda v: str(v))
+def test_rgb_head_data_gradient_accumulates_into_a_slice(dev, n, cin, h):
+    """dcv_conv_backward_data(accumulate = 1) into the last `cin` channels of a wider buffer that already holds a gradient (how the U-Net's skip
+    connections receive theirs, ops.GradSlot): the neighbouring channels stay untouched, the slice gets old + new."""
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    g = torch.Generator().manual_seed(7 + n + cin)
+    w = torch.randn(cin, 3, 3, 3, generator=g) * 0.1
+    x = torch.randn(n, cin, h, 64, generator=g, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad((y * dy).sum(), [x])
+    wide = torch.randn(n, cin + 5, h, 64, generator=g)
+    want = wide.clone(); want[:, 5:] += gx
+    wide_d, dy_d, w_d = wide.to(dev), dy.to(dev), w.to(dev)
+    dx = wide_d[:, 5:]
+    geom = ops.conv_geom(w_d, (1, 1), (1, 1), True)
+    dxd, dyd = dims5(dx), dims5(dy_d)
+    L = N.lib()
+    need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(dxd), C.byref(dyd), 1)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    N.check(L.dcv_conv_backward_data(C.byref(geom), ptr(dy_d), C.byref(dyd), ptr(w_d), ptr(dx), C.byref(dxd), 1, None, ptr(ws), need, stream_ptr()), "accumulate")
+    assert "widen_mfma_kernel" in last_kernel(), last_kernel()
+    assert rel(wide_d, want) < 1e-5
+    assert torch.equal(wide_d[:, :5].cpu(), wide[:, :5])
+
+
+def test_rgb_head_weight_gradient_accumulates(dev):
+    """dcv_conv_backward_weight_acc: the slab reduce adds into what dw holds (second use of a weight in one backward)."""
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    g = torch.Generator().manual_seed(21)
+    n, cin, h = 6, 128, 16
+    w = (torch.randn(cin, 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    x = torch.randn(n, cin, h, 64, generator=g)
+    dy = torch.randn(n, 3, h, 64, generator=g)
+    (gw,) = torch.autograd.grad((F.conv_transpose2d(x, w, None, 1, 1) * dy).sum(), [w])
+    old = torch.randn(w.shape, generator=g)
+    xd, dyd_, dwd = x.to(dev), dy.to(dev), old.to(dev)
+    geom = ops.conv_geom(w.detach().to(dev), (1, 1), (1, 1), True)
+    xdm, dym = dims5(xd), dims5(dyd_)
+    L = N.lib()
+    need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(xdm), C.byref(dym), 2)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    N.check(L.dcv_conv_backward_weight_acc(C.byref(geom), ptr(xd), C.byref(xdm), ptr(dyd_), C.byref(dym), ptr(dwd), 1, ptr(ws), need, stream_ptr()), "wgrad acc")
+    assert "thinj_wgrad_kernel" in last_kernel(), last_kernel()
+    assert rel(dwd, old + gw) < 2e-5

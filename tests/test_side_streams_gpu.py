@@ -93,3 +93,52 @@ def test_a_module_at_another_precision_on_the_next_stream_changes_nothing():
         torch.cuda.synchronize()
         bad = [k for k in ref if not torch.equal(got[k], ref[k])]
         assert not bad, (t, bad[:4])
+
+
+def test_companion_stream_is_refused_where_autograd_would_touch_its_result():
+    """the weight gradient on the companion stream is only safe where AccumulateGrad adopts the tensor without a kernel of its own.  The cases where it
+    would launch one (a .grad the in-place sum refuses, create_graph, post-accumulate hooks) stay in-stream; a backward under each still gives the in-stream result."""
+    from dcvgan_amd import native, ops
+    native.lib()
+    dev = torch.device("cuda:0")
+    w = torch.nn.Parameter(torch.randn(8, 4, 4, 4, device=dev) * 0.1)
+    with torch.no_grad():                                   # a backward node runs with grad mode off ...
+        assert ops.wgrad_companion(dev, w) is not None
+        w.grad = torch.zeros(4, 8, 4, 4, device=dev).permute(1, 0, 2, 3)      # not contiguous: autograd adds, on the chain's stream
+        assert ops.wgrad_companion(dev, w) is None
+        w.grad = torch.zeros_like(w)
+        assert ops.wgrad_companion(dev, w) is not None
+        w.grad = None
+        h = w.register_post_accumulate_grad_hook(lambda p: None)
+        assert ops.wgrad_companion(dev, w) is None
+        h.remove()
+        assert ops.wgrad_companion(dev, w) is not None
+    assert ops.wgrad_companion(dev, w) is None              # ... unless create_graph=True keeps it on: AccumulateGrad clones then
+
+    g = ops.conv_geom(w, (2, 2), (1, 1), False)
+    x = torch.randn(3, 4, 16, 16, device=dev)
+    cot = torch.randn(3, 8, 8, 8, device=dev)
+
+    def dw(prepare):
+        w.grad = None
+        handle = prepare()
+        (ops.conv(x, w, g) * cot).sum().backward()
+        torch.cuda.synchronize()
+        if handle is not None:
+            handle.remove()
+        out = w.grad.detach().clone()
+        w.grad = None
+        return out
+    seen = []
+    base = dw(lambda: None)
+    hooked = dw(lambda: w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.detach().clone())))
+    assert torch.equal(base, hooked) and len(seen) == 1 and torch.equal(seen[0], base)      # the hook read a complete gradient
+
+    def preset():
+        w.grad = torch.ones(4, 8, 4, 4, device=dev).permute(1, 0, 2, 3)
+    w.grad = None
+    preset()
+    (ops.conv(x, w, g) * cot).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(w.grad, base + 1.0, rtol=0, atol=1e-5 * float(base.abs().max()))
+    w.grad = None

@@ -25,7 +25,8 @@ ap.add_argument("--batch", type=int, default=0)
 ap.add_argument("--csv", default="")
 ap.add_argument("--filter", default="")
 ap.add_argument("--plan", default="")
-ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--reps", type=int, default=20)      # timed launches per row, after --warm untimed ones: the SUSTAINED figure (clocks settled), the one
+ap.add_argument("--warm", type=int, default=10)      # rocprofv3's per-dispatch durations inside the iteration and bench.py's probe agree with
 ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f32x6", "bf16cl"])
 a = ap.parse_args()
 cfg = CONFIGS[a.config]
@@ -81,7 +82,9 @@ add(f"gdis.13 conv3d {4 * dg}->1", False, 4 * dg, 1, K3, S3, P3, (B, 4 * dg, 6, 
 
 
 def timeit(fn, reps):
-    fn(); fn(); torch.cuda.synchronize()
+    for _ in range(max(2, a.warm)):
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -190,7 +193,7 @@ ts = sum(tot.values())
 print("per-iteration conv time (ms): fwd %.1f dgrad %.1f wgrad %.1f total %.1f ; %.1f TF/s avg = %.3f of the %s MFMA peak" % (tot["fwd"], tot["dgrad"], tot["wgrad"], ts, totf / ts, totf / ts / PEAK, a.precision))
 if a.csv:
     with open(a.csv, "w") as f:
-        f.write(f"# {a.config}, per-GPU batch {B}; HIP events, {a.reps} reps; launches_per_iteration follows trainer.py:279-363 (gating averaged)\n")
+        f.write(f"# {a.config}, per-GPU batch {B}; HIP events, {a.reps} timed launches after {max(2, a.warm)} untimed; launches_per_iteration follows trainer.py:279-363 (gating averaged)\n")
         f.write(f"layer,op,kernel,gflop,ms,tflops,frac_of_{a.precision}_mfma_peak,launches_per_iteration\n")
         for r in rows:
             f.write('"%s",%s,"%s",%.2f,%.4f,%.1f,%.3f,%.2f\n' % r)
