@@ -3772,7 +3772,7 @@ int dcv_set_precision(int mode) {
     return DCV_OK;
 }
 int dcv_get_precision(void) { return g_precision.load(); }
-int dcv_version(void) { return 3; }
+int dcv_version(void) { return 4; }
 void dcv_abi_struct_sizes(size_t out[3]) {
     if (!out) return;
     out[0] = sizeof(dcv_dims5); out[1] = sizeof(dcv_conv_geom); out[2] = sizeof(dcv_wpack);

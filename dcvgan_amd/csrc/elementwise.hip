@@ -150,12 +150,21 @@ static int launch_ew(const RowMap& m, const F& f, hipStream_t s) {
 template <int VEC> struct Vec;
 template <> struct Vec<4> { typedef float4 T; };
 template <> struct Vec<1> { typedef float T; };
+typedef float ew_f4 __attribute__((ext_vector_type(4)));
+// DCV_EW_NT (A/B builds): non-temporal loads / stores in the streaming kernels (every byte is touched once per pass)
+#ifdef DCV_EW_NT
+#define DCV_EW_LD4(P) __builtin_nontemporal_load(reinterpret_cast<const ew_f4*>(P))
+#define DCV_EW_ST4(P, V) __builtin_nontemporal_store((V), reinterpret_cast<ew_f4*>(P))
+#else
+#define DCV_EW_LD4(P) (*reinterpret_cast<const ew_f4*>(P))
+#define DCV_EW_ST4(P, V) (*reinterpret_cast<ew_f4*>(P) = (V))
+#endif
 template <int VEC> __device__ __forceinline__ void ld(const float* p, float (&v)[VEC]) {
-    if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    if constexpr (VEC == 4) { const ew_f4 t = DCV_EW_LD4(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     else v[0] = *p;
 }
 template <int VEC> __device__ __forceinline__ void st(float* p, const float (&v)[VEC]) {
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    if constexpr (VEC == 4) { const ew_f4 t = {v[0], v[1], v[2], v[3]}; DCV_EW_ST4(p, t); }
     else *p = v[0];
 }
 
@@ -503,9 +512,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(ChanMap m, cons
         const float mk = mask ? mask[(int64_t)n * m.C + c] : 1.f;
 #pragma unroll 4
         for (int g = 0; g < m.gpr; g += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(xr + 4 * g);
-            const float4 dd = *reinterpret_cast<const float4*>(dr + 4 * g);
-            const float vv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
+            const ew_f4 v = DCV_EW_LD4(xr + 4 * g);
+            const ew_f4 dd = DCV_EW_LD4(dr + 4 * g);
+            const float vv[4] = {v[0], v[1], v[2], v[3]}, dv[4] = {dd[0], dd[1], dd[2], dd[3]};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float xh = (vv[i] - mu) * is;
@@ -1283,6 +1292,20 @@ int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, c
     DCV_LAUNCH_CHECK();
     BnBwdApply f{dy, x, dx, rv(*dyd), rv(*xd), rv(*dxd), gamma, beta, save_mean, save_invstd, mask, coef, act, slope, training};
     return launch_ew(m, f, s);
+}
+
+// y[i] = x[i] * *s: the chain rule through a loss term — the upstream cotangent is a 0-d DEVICE tensor (loss.backward(), trainer.py:319,356)
+__global__ __launch_bounds__(256) void scale_dev_kernel(const float* __restrict__ x, int64_t n, const float* __restrict__ s, float* __restrict__ y) {
+    const float k = *s;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = x[i] * k;
+}
+
+int dcv_scale_dev(const float* x, int64_t n, const float* s, float* y, void* stream) {
+    if (!x || !s || !y || n < 0) return fail(DCV_EINVAL, "scale_dev: bad arguments");
+    if (n == 0) return DCV_OK;
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, s, y);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
 }
 
 int dcv_gan_loss(const float* y, int64_t n, int kind, float* loss_out, int accumulate, float* dy_out, void* stream) {

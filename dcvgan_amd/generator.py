@@ -75,7 +75,7 @@ class GeometricVideoGenerator(nn.Module):
 
     def sample_z_content(self, batchsize: int) -> torch.Tensor:
         zc = self._source().normal((batchsize, self.dim_z_content), self.device)
-        return zc.unsqueeze(1).expand(batchsize, self.video_length, self.dim_z_content).reshape(-1, self.dim_z_content)
+        return ops.tile_rows(zc, self.video_length)      # every clip's content latent for each of its frames
 
     def sample_z_video(self, batchsize: int) -> torch.Tensor:
         zc = self.sample_z_content(batchsize)
@@ -218,7 +218,7 @@ class ColorVideoGenerator(nn.Module):
     def forward_videos(self, xs: torch.Tensor) -> torch.Tensor:
         B, Cg, T, H, W = xs.shape
         z = self.make_hidden(B)
-        zs = z.unsqueeze(1).expand(B, T, self.dim_z, 1, 1).reshape(B * T, self.dim_z, 1, 1)
+        zs = ops.tile_rows(z.view(B, self.dim_z), T).view(B * T, self.dim_z, 1, 1)
         to_frames = lambda v: v.permute(0, 2, 1, 3, 4).reshape(B * T, Cg, H, W)  # a view for generator outputs
         frames = to_frames(xs)
         if ops_cl.active() and frames.data_ptr() == xs.data_ptr():      # (a copy has no twin: its bits are its own)

@@ -1,5 +1,5 @@
 """GAN losses with the reference's Loss interface (loss.py:9-193), each term one
-fused value+gradient HIP kernel (ops.gan_loss)."""
+fused value+gradient HIP kernel, the terms of a loss summed on the device (ops.gan_loss_sum)."""
 from __future__ import annotations
 
 from abc import ABCMeta, abstractmethod
@@ -73,11 +73,10 @@ class AdversarialLoss(Loss):
         self.device = util.current_device()
 
     def compute_dis_loss(self, y_real, y_fake):
-        return HostMirroredLoss.wrap(ops.gan_loss(y_real, ops.KIND_BCE_ONES) + ops.gan_loss(y_fake, ops.KIND_BCE_ZEROS))
+        return HostMirroredLoss.wrap(ops.gan_loss_sum([(y_real, ops.KIND_BCE_ONES), (y_fake, ops.KIND_BCE_ZEROS)]))
 
     def compute_gen_loss(self, y_fake_i, y_fake_v, y_fake_g):
-        return HostMirroredLoss.wrap(ops.gan_loss(y_fake_i, ops.KIND_BCE_ONES) + ops.gan_loss(y_fake_v, ops.KIND_BCE_ONES)
-                                     + ops.gan_loss(y_fake_g, ops.KIND_BCE_ONES))
+        return HostMirroredLoss.wrap(ops.gan_loss_sum([(y_fake_i, ops.KIND_BCE_ONES), (y_fake_v, ops.KIND_BCE_ONES), (y_fake_g, ops.KIND_BCE_ONES)]))
 
 
 class HingeLoss(Loss):
@@ -89,7 +88,7 @@ class HingeLoss(Loss):
         self.device = util.current_device()
 
     def compute_dis_loss(self, y_real, y_fake):
-        return HostMirroredLoss.wrap(ops.gan_loss(y_real, ops.KIND_HINGE_REAL) + ops.gan_loss(y_fake, ops.KIND_HINGE_FAKE))
+        return HostMirroredLoss.wrap(ops.gan_loss_sum([(y_real, ops.KIND_HINGE_REAL), (y_fake, ops.KIND_HINGE_FAKE)]))
 
     def compute_gen_loss(self, y_fake_i, y_fake_v, y_fake_g):
-        return HostMirroredLoss.wrap(ops.gan_loss(y_fake_i, ops.KIND_SOFTPLUS_NEG) + ops.gan_loss(y_fake_v, ops.KIND_SOFTPLUS_NEG))
+        return HostMirroredLoss.wrap(ops.gan_loss_sum([(y_fake_i, ops.KIND_SOFTPLUS_NEG), (y_fake_v, ops.KIND_SOFTPLUS_NEG)]))

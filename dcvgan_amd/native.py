@@ -90,6 +90,7 @@ _SIGS = {
     "dcv_videos_to_uint8": (C.c_int, [_P, _D, _P, C.c_int, _P]),
     "dcv_flow_to_rgb": (C.c_int, [_P, _D, C.c_float, _P, _P, _P]),
     "dcv_gan_loss": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int, _P, _P]),
+    "dcv_scale_dev": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "dcv_gru_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "dcv_gru_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dcv_gru_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
@@ -135,7 +136,7 @@ _SIGS = {
 }
 EXPORTS = tuple(_SIGS)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 _lock = threading.Lock()
 

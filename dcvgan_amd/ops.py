@@ -123,11 +123,18 @@ class _PackCache:
             nbytes = lib().dcv_conv_packed_bytes(C.byref(g), C.byref(xd), C.byref(yd), which)
             if nbytes == 0:
                 return None
-            e = self.entries[key] = [None, torch.empty(nbytes, dtype=torch.uint8, device=w.device)]
+            e = self.entries[key] = [None, torch.empty(nbytes, dtype=torch.uint8, device=w.device), None, None]
         ready = e[0] == stamp
+        if w.is_cuda:
+            cur = torch.cuda.current_stream(w.device)
+            if e[2] is not None and e[3] != cur.cuda_stream:
+                # packed (or last repacked) by a launch on another stream — a discriminator lane, the D phase's generator stream: this stream's kernels read the
+                # buffer behind that launch.  (A stream still READING old tiles is not waited for by a repack: a repack follows an optimiser step, and every
+                # consumer of the old weights is ordered before that step.)
+                cur.wait_event(e[2])
         e[0] = None                     # not valid again until the launch that (re)packs it has been accepted: see commit()
         pk = N.WPack(e[1].data_ptr(), e[1].numel(), int(ready), prec)
-        pk._entry, pk._stamp = e, stamp
+        pk._entry, pk._stamp, pk._packs = e, stamp, not ready
         return pk
 
     @staticmethod
@@ -135,7 +142,14 @@ class _PackCache:
         """The conv call that consumed `pk` returned success: its packed buffer now holds the weights of `stamp`.  A call that
         fails (EWORKSPACE, a launch error) never gets here, so a retry packs again instead of reading an unpacked buffer."""
         if pk is not None:
-            pk._entry[0] = pk._stamp
+            e = pk._entry
+            e[0] = pk._stamp
+            if pk._packs and e[1].is_cuda:      # this call wrote the buffer: other streams order themselves behind it (get())
+                cur = torch.cuda.current_stream(e[1].device)
+                if e[2] is None:
+                    e[2] = torch.cuda.Event()
+                e[2].record(cur)
+                e[3] = cur.cuda_stream
 
 
 _USE_PACK_CACHE = os.environ.get("DCV_NO_PACK_CACHE") is None
@@ -710,25 +724,123 @@ KIND_BCE_ONES, KIND_BCE_ZEROS, KIND_HINGE_REAL, KIND_HINGE_FAKE, KIND_SOFTPLUS_N
 
 
 class _GanLoss(Function):
+    """Sum of GAN loss terms (one fused value + gradient launch per term, the value accumulated on the device: `l_real + l_fake` of loss.py:99,131,164 without
+    a torch add); backward: each term's stored gradient times the upstream 0-d cotangent, read on the device (dcv_scale_dev)."""
+
     @staticmethod
-    def forward(ctx, y, kind: int):
-        N._require(y, "loss input")
-        yc = y.contiguous()
-        out = _empty((), y.device)
-        dy = _empty(yc.shape, yc.device)
-        check(lib().dcv_gan_loss(ptr(yc), yc.numel(), kind, ptr(out), 0, ptr(dy), stream_ptr()), "dcv_gan_loss")
-        ctx.save_for_backward(dy)
-        ctx.shape = tuple(y.shape)
+    def forward(ctx, kinds, *ys):
+        out = _empty((), ys[0].device)
+        dys = []
+        for i, (y, kind) in enumerate(zip(ys, kinds.v)):
+            N._require(y, "loss input")
+            yc = y.contiguous()
+            dy = _empty(yc.shape, yc.device)
+            check(lib().dcv_gan_loss(ptr(yc), yc.numel(), int(kind), ptr(out), int(i > 0), ptr(dy), stream_ptr()), "dcv_gan_loss")
+            dys.append(dy)
+        ctx.save_for_backward(*dys)
+        ctx.shapes = [tuple(y.shape) for y in ys]
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (dy,) = ctx.saved_tensors
-        return (dy * g).view(ctx.shape), None
+        if not (g.is_cuda and g.dtype == torch.float32):
+            raise N.NativeError("gan_loss backward: the upstream cotangent must be an fp32 device tensor")
+        g = g.reshape(())
+        outs = []
+        for dy, shape, need in zip(ctx.saved_tensors, ctx.shapes, ctx.needs_input_grad[1:]):
+            if not need:
+                outs.append(None)
+                continue
+            dx = _empty(dy.shape, dy.device)
+            check(lib().dcv_scale_dev(ptr(dy), dy.numel(), ptr(g), ptr(dx), stream_ptr()), "dcv_scale_dev")
+            outs.append(dx.view(shape))
+        return (None,) + tuple(outs)
 
 
 def gan_loss(y, kind: int):
-    return _GanLoss.apply(y, kind)
+    return _GanLoss.apply(_Opaque((kind,)), y)
+
+
+def gan_loss_sum(terms):
+    """sum_i loss(y_i, kind_i) for [(y, kind), ...], summed on the device in list order."""
+    return _GanLoss.apply(_Opaque(tuple(k for _, k in terms)), *[y for y, _ in terms])
+
+
+class _SumScalars(Function):
+    """((x0 + x1) + x2) ... of 0-d tensors by dcv_axpby — `loss_idis + loss_vdis + loss_gdis` (trainer.py:315) without torch's add kernels; every term receives
+    the upstream cotangent itself."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        for x in xs:
+            N._require(x, "sum_scalars operand")
+        acc = xs[0]
+        for x in xs[1:]:
+            out = _empty((), x.device)      # (0-d and nobody's view: the trainer calls detach_() on the result, trainer.py:324)
+            _axpby(acc.reshape(1, 1), 1.0, x.reshape(1, 1), 1.0, out.view(1, 1))
+            acc = out
+        ctx.n = len(xs)
+        return acc if len(xs) > 1 else acc.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+def sum_scalars(*xs):
+    return _SumScalars.apply(*xs)
+
+
+class _FanOut(Function):
+    """One tensor read by several consumers — the fake clips feed the image discriminator (frame `t`), the video and the gradient discriminator, and the
+    geometry clip the colour generator as well (trainer.py:303-309,346-349): the outputs are views of x (frame x[:, :, t] first, then `n_full` whole-tensor
+    aliases), and the backward forms the ONE gradient of x with dcv_axpby — whole-tensor cotangents in output order, then the frame's into its slice — where
+    autograd would launch a torch add per extra consumer plus the zero-fill and copy of the slice's backward."""
+
+    @staticmethod
+    def forward(ctx, x, t, n_full):
+        N._require(x, "fan_out input")
+        ctx.t, ctx.shape, ctx.strides = int(t), tuple(x.shape), tuple(x.stride())      # the generators' clips are (B, T, C, H, W) memory viewed as (B, C, T, H, W)
+        order = sorted(range(x.dim()), key=lambda i: -ctx.strides[i])
+        ctx.dense = x.permute(*order).is_contiguous()
+        ctx.set_materialize_grads(False)
+        return (x[:, :, ctx.t],) + tuple(x.view_as(x) for _ in range(int(n_full)))
+
+    @staticmethod
+    def backward(ctx, g_frame, *g_full):
+        gs = [_dense(g) for g in g_full if g is not None]
+        if not gs and g_frame is None:
+            return None, None, None
+        dev = (gs[0] if gs else g_frame).device
+        # x's own layout when it is a dense permutation (the view chain back into the generator then needs no copy), else contiguous
+        tot = torch.empty_strided(ctx.shape, ctx.strides, dtype=torch.float32, device=dev) if ctx.dense else _empty(ctx.shape, dev)
+        if not gs:
+            raise N.NativeError("fan_out: only the frame consumer delivered a gradient (no whole-tensor consumer): not a case of the training iteration")
+        if len(gs) == 1:
+            _axpby(gs[0], 1.0, None, 0.0, tot)
+        else:
+            _axpby(gs[0], 1.0, gs[1], 1.0, tot)
+            for g in gs[2:]:
+                _axpby(tot, 1.0, g, 1.0, tot)
+        if g_frame is not None:
+            sl = tot[:, :, ctx.t]
+            _axpby(sl, 1.0, _dense(g_frame), 1.0, sl)
+        return tot, None, None
+
+
+def fan_out(x, t: int, n_full: int):
+    """(x[:, :, t], x, x, ...) with `n_full` whole-tensor aliases; see _FanOut."""
+    return _FanOut.apply(x, int(t), int(n_full))
+
+
+def tile_rows(z, reps: int):
+    """(B, C) -> (B * reps, C): every row `reps` times (`zc.repeat(1, T).view(B * T, C)`, generator.py:85-91,356-360) as ONE strided dcv_axpby read of a
+    broadcast view — z carries no gradient (a latent draw)."""
+    N._require(z, "tile_rows input")
+    B, Cc = z.shape
+    out = _empty((B * reps, Cc), z.device)
+    _axpby(z.view(B, 1, 1, 1, Cc).expand(B, reps, 1, 1, Cc), 1.0, None, 0.0, out.view(B, reps, 1, 1, Cc))
+    return out
 
 
 # --------------------------------------------------------------------------- #
@@ -745,14 +857,18 @@ class _GruSeq(Function):
         out = _empty((B, T, dm), e.device)
         gates = _empty((T, B, 4 * dm), e.device)
         check(lib().dcv_gru_forward(ptr(e), ptr(h0), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(out), ptr(gates), T, B, dm, stream_ptr()), "dcv_gru_forward")
-        ctx.save_for_backward(e, h0, out, gates, w_ih, w_hh)
+        ctx.save_for_backward(e, h0, out, gates, w_ih, w_hh, b_ih, b_hh)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        e, h0, out, gates, w_ih, w_hh = ctx.saved_tensors
+        e, h0, out, gates, w_ih, w_hh, b_ih, b_hh = ctx.saved_tensors
         T, B, dm = e.shape
-        dout = dout.contiguous()
+        if not dout.is_contiguous():      # a channel slice of the latent's gradient (cat_channels): the library's strided copy, not torch's
+            src = dout.reshape(T * B, dm)      # (a view: the slice is row-strided)
+            dense = _empty((B, T, dm), e.device)
+            _axpby(src, 1.0, None, 0.0, dense.view(T * B, dm))
+            dout = dense
         dw_ih, dw_hh = _empty(w_ih.shape, w_ih.device), _empty(w_hh.shape, w_hh.device)
         db_ih = _empty((3 * dm,), e.device)
         db_hh = _empty((3 * dm,), e.device)
@@ -760,7 +876,10 @@ class _GruSeq(Function):
         wsp, wsn = _ws("gru", L.dcv_gru_workspace_bytes(B, dm), e.device)
         check(L.dcv_gru_backward(ptr(dout), ptr(e), ptr(h0), ptr(out), ptr(gates), ptr(w_ih), ptr(w_hh), ptr(dw_ih), ptr(dw_hh), ptr(db_ih), ptr(db_hh),
                                  T, B, dm, wsp, wsn, stream_ptr()), "dcv_gru_backward")
-        return None, None, dw_ih, dw_hh, db_ih, db_hh
+        # second and later contributions (the dead D-phase backward adds to the last G phase's gradients) by dcv_axpby, not by autograd's torch add
+        if not _OWN_ACCUMULATION:
+            return None, None, dw_ih, dw_hh, db_ih, db_hh
+        return (None, None) + tuple(deliver_small(p, t) for p, t in zip((w_ih, w_hh, b_ih, b_hh), (dw_ih, dw_hh, db_ih, db_hh)))
 
 
 def gru_sequence(e, h0, w_ih, w_hh, b_ih, b_hh):

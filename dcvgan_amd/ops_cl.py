@@ -53,14 +53,22 @@ def pitch_of(c: int) -> int:
     return 8 if c <= 8 else (c + 31) // 32 * 32
 
 
+_ZEROS = {}
+
+
 def cl_empty(shape, device, pitch: Optional[int] = None, zero: bool = False) -> torch.Tensor:
     """(N, C, [D,] H, W) bf16 tensor in channels-last memory.  Every kernel that produces a CL16 tensor writes whole 8-channel groups (zeros past C), and
     every kernel that reads one stops at C rounded up to 8, so a fresh tensor needs no clearing; `zero=True` is for buffers whose channels are filled
     piecewise (a concatenation whose total is not a multiple of 8)."""
     n, c, sp = shape[0], shape[1], tuple(shape[2:])
     p = pitch if pitch is not None else pitch_of(c)
-    make = torch.zeros if zero else torch.empty
-    store = make((n,) + sp + (p,), dtype=_HALF[0], device=device)
+    store = torch.empty((n,) + sp + (p,), dtype=_HALF[0], device=device)
+    if zero:      # a device-to-device copy of a cached block of zeros (torch.zeros would launch one of torch's fill kernels in every iteration)
+        key = (str(device), _HALF[0], store.numel())
+        z = _ZEROS.get(key)
+        if z is None:
+            z = _ZEROS[key] = torch.zeros(store.numel(), dtype=_HALF[0], device=device)
+        store.view(-1).copy_(z)
     perm = (0, len(sp) + 1) + tuple(range(1, len(sp) + 1))
     return store.permute(*perm)[:, :c]
 

@@ -81,6 +81,29 @@ class Adam:
             torch.autograd.graph.increment_version(touched)
 
 
+def _copy_into(slot: torch.Tensor, g: torch.Tensor) -> None:
+    """slot <- g with the library's strided copy (dcv_axpby) on the device; torch's copy on the host (gloo rehearsals)."""
+    if slot.is_cuda and g.dtype == torch.float32 and g.dim() in (2, 4, 5):
+        from . import ops
+        ops._axpby(g, 1.0, None, 0.0, slot)
+    elif slot.is_cuda and g.dtype == torch.float32:
+        from . import ops
+        ops._axpby(g.reshape(1, -1) if g.is_contiguous() else g.contiguous().reshape(1, -1), 1.0, None, 0.0, slot.reshape(1, -1))
+    else:
+        slot.copy_(g)
+
+
+def _zero_slot(p) -> None:
+    """p's gradient slice <- 0.  On the device: 0 * p (the parameter is finite where the stale slice need not be) through dcv_axpby, so that no torch fill
+    kernel runs beside the library's (DESIGN: packed-FP32 code of torch's elementwise kernels is outside the build's control)."""
+    slot = p._dcv_grad_slot
+    if slot.is_cuda:
+        from . import ops
+        ops._axpby(p.detach().reshape(1, -1), 0.0, None, 0.0, slot.reshape(1, -1))
+    else:
+        slot.zero_()
+
+
 class GradBucket:
     """The gradients that one backward produces and one group of optimiser steps consumes.
 
@@ -169,7 +192,7 @@ class GradBucket:
             self._layout()
         g, slot = p.grad, p._dcv_grad_slot
         if g is not None and g.data_ptr() != slot.data_ptr():
-            slot.copy_(g)
+            _copy_into(slot, g)
             p.grad = slot
             self.copies += 1
         if self.overlap:
@@ -229,7 +252,7 @@ class GradBucket:
                         self._comm.wait_event(e)
                     for q in c.members:          # slices of members without a gradient this backward: zeroed before they are summed over the ranks
                         if q.grad is None:
-                            q._dcv_grad_slot.zero_()
+                            _zero_slot(q)
                     c.work = self.dist.all_reduce(flat[c.a:c.b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
                 flat.record_stream(self._comm)
             else:
@@ -273,9 +296,9 @@ class GradBucket:
             if c.work is None:      # not launched during the backward: now, on the current stream
                 for p in c.members:
                     if p.grad is None:
-                        p._dcv_grad_slot.zero_()      # no gradient this backward: the stale slice must not be summed over the ranks again and again
+                        _zero_slot(p)                 # no gradient this backward: the stale slice must not be summed over the ranks again and again
                     elif p.grad.data_ptr() != p._dcv_grad_slot.data_ptr():
-                        p._dcv_grad_slot.copy_(p.grad)
+                        _copy_into(p._dcv_grad_slot, p.grad)
                         p.grad = p._dcv_grad_slot
                         self.copies += 1
                 self._launch(c, early=False)

@@ -21,7 +21,7 @@ import torch
 from . import discriminator as D
 from . import generator as G
 from . import loss as Lm
-from . import optim, util
+from . import ops, optim, util
 from .configs import StepConfig
 
 MODEL_NAMES = ("ggen", "cgen", "idis", "vdis", "gdis")
@@ -82,6 +82,15 @@ class StepRunner:
             self._lanes = [torch.cuda.Stream(dev) for _ in range(3)]
         if cfg.start_in_eval:  # trainer.py:266-267: log_samples/evaluate leave the generators in eval()
             models["ggen"].eval(); models["cgen"].eval()
+        # diagnostics (tools/phases.py): HIP events on the main stream at the phase boundaries of an iteration; None = off (no event is ever recorded)
+        self.phase_marks = None
+        self._ones = {}
+
+    def _mark(self, name):
+        if self.phase_marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            self.phase_marks.append((name, e))
 
     # The three discriminators are independent of one another (trainer.py:299-309, 347-349): each runs on its own HIP stream, so
     # their small layers (70-frame image discriminator, the 1-channel heads, BN reductions) and the tail rounds of the large ones
@@ -109,6 +118,29 @@ class StepRunner:
             main.wait_stream(lane)
             y.record_stream(main)           # allocated on the lane, read by the loss kernels on the main stream
 
+    # The fake clips are read by three discriminators — the image discriminator takes frame t_rand — and the geometry clip by the colour generator too
+    # (trainer.py:303-309, 344-349).  ops.fan_out hands every consumer a view and forms the clip's ONE gradient with the library's kernels; left to autograd the fan-in
+    # is a torch add per extra consumer plus the zero-fill + copy of each slice's backward (18 + ~25 torch launches per iteration in round 5's traces).
+    def _colour(self, cgen, xg_fake, t_rand):
+        """-> ((frame, for vdis, for gdis) of the geometry clip, the same of the colour clip cgen makes of it)"""
+        if not (xg_fake.is_cuda and xg_fake.requires_grad):
+            xc = cgen.forward_videos(xg_fake)
+            return (xg_fake[:, :, t_rand], xg_fake, xg_fake), (xc[:, :, t_rand], xc, xc)
+        g_i, g_c, g_v, g_g = ops.fan_out(xg_fake, t_rand, 3)
+        c_i, c_v, c_g = ops.fan_out(cgen.forward_videos(g_c), t_rand, 2)
+        return (g_i, g_v, g_g), (c_i, c_v, c_g)
+
+    def _fakes_through(self, dis, idis, xg, xc, t_rand):
+        which = {id(d): k for k, d in enumerate(dis)}
+        return self._on_lanes(dis, lambda d: d(xg[which[id(d)]], xc[which[id(d)]]))
+
+    def _root(self, loss):
+        """d loss / d loss = 1 as a cached device scalar (backward() without an argument fills a fresh ones_like with a torch kernel)."""
+        one = self._ones.get(loss.device)
+        if one is None:
+            one = self._ones[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return one
+
     def step(self, xc_real: torch.Tensor, xg_real: torch.Tensor, t_rand: int):
         c, m, o = self.cfg, self.models, self.opt
         ggen, cgen, idis, vdis, gdis = (m[k] for k in MODEL_NAMES)
@@ -119,19 +151,24 @@ class StepRunner:
         for d in (idis, vdis, gdis):
             d.zero_grad()
         dis = (idis, vdis, gdis)
+        self._mark("start")
         y_real = self._on_lanes(dis, lambda d: d(xg_real[:, :, t_rand], xc_real[:, :, t_rand]) if d is idis else d(xg_real, xc_real), join=False)
         with torch.set_grad_enabled(not self.elide_dead_backward):
             xg_fake = ggen.sample_videos(c.batchsize)     # on the main stream, beside the discriminators' real-batch passes
-            xc_fake = cgen.forward_videos(xg_fake)
-        y_fake = self._on_lanes(dis, lambda d: d(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]) if d is idis else d(xg_fake, xc_fake))
+            xg_fake, xc_fake = self._colour(cgen, xg_fake, t_rand)
+        self._mark("D: generators forward (beside D on the real batch)")
+        y_fake = self._fakes_through(dis, idis, xg_fake, xc_fake, t_rand)
         self._adopt(y_real)
+        self._mark("D: discriminators forward on the fakes")
         loss_idis = self.loss.compute_dis_loss(y_real[0], y_fake[0])
         loss_vdis = self.loss.compute_dis_loss(y_real[1], y_fake[1])
         loss_gdis = self.loss.compute_dis_loss(y_real[2], y_fake[2])
-        loss_dis = loss_idis + loss_vdis + loss_gdis
+        loss_dis = ops.sum_scalars(loss_idis, loss_vdis, loss_gdis) if loss_idis.is_cuda else loss_idis + loss_vdis + loss_gdis      # trainer.py:315
         if self.iteration % c.num_gen_update == 0:
-            loss_dis.backward()
+            loss_dis.backward(self._root(loss_dis))
+            self._mark("D: backward (D lanes, then the generators' dead backward)")
             o["idis"].step(); o["vdis"].step(); o["gdis"].step()
+            self._mark("D: Adam")
         else:
             loss_dis.detach_()
         if self.sync_losses:   # trainer.py:326-328 — on the loss objects themselves, as the reference reads them (they carry a host mirror: loss.HostMirroredLoss)
@@ -143,12 +180,16 @@ class StepRunner:
         ggen.train(); cgen.train()
         ggen.zero_grad(); cgen.zero_grad()
         xg_fake = ggen.sample_videos(c.batchsize)
-        xc_fake = cgen.forward_videos(xg_fake)
-        y_fake = self._on_lanes(dis, lambda d: d(xg_fake[:, :, t_rand], xc_fake[:, :, t_rand]) if d is idis else d(xg_fake, xc_fake))
+        xg_fake, xc_fake = self._colour(cgen, xg_fake, t_rand)
+        self._mark("G: generators forward")
+        y_fake = self._fakes_through(dis, idis, xg_fake, xc_fake, t_rand)
         loss_gen = self.loss.compute_gen_loss(*y_fake)
+        self._mark("G: discriminators forward on the fakes")
         if self.iteration % c.num_dis_update == 0:
-            loss_gen.backward()
+            loss_gen.backward(self._root(loss_gen))
+            self._mark("G: backward (D lanes, then the generators)")
             o["ggen"].step(); o["cgen"].step(); o["ggen"].step()  # ggen twice — trainer.py:357-359
+            self._mark("G: Adam")
         else:
             loss_gen.detach_()
         out["loss_gen"] = loss_gen.cpu().item() if self.sync_losses else loss_gen.detach()     # trainer.py:363

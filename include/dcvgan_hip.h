@@ -63,7 +63,7 @@ typedef struct dcv_conv_geom {
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
-/* ABI version.  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
+/* ABI version.  4 (round 6): dcv_scale_dev exists (no struct changed).  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
  * 2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
  * A host compares dcv_version() and dcv_abi_struct_sizes() with its own declarations BEFORE the first call that passes a struct
  * (dcvgan_amd/native.py does, and refuses to load on a mismatch): the library cannot see the size of what a pointer points to. */
@@ -241,6 +241,9 @@ int dcv_flow_to_rgb(const float* flow, const dcv_dims5* fd, float scale, uint8_t
  * 2 = mean(relu(1 - y)), 3 = mean(relu(1 + y)), 4 = mean(softplus(-y)).
  * *loss_out (+)= value ; dy_out[i] = d value / d y[i].                        */
 int dcv_gan_loss(const float* y, int64_t n, int kind, float* loss_out, int accumulate, float* dy_out, void* stream);
+/* y[i] = x[i] * *s, s a 0-d DEVICE scalar: the backward of a loss term — `loss.backward()` (trainer.py:319,356) hands every
+ * term of loss.py:99,131,164,191 the upstream cotangent as a device tensor; dy_out of dcv_gan_loss times it, without a host read. */
+int dcv_scale_dev(const float* x, int64_t n, const float* s, float* y, void* stream);
 
 /* ---- GRUCell (generator.py:58,94) --------------------------------------- *
  * The whole T-step motion-latent recurrence in one launch: h_t = GRU(e_t, h_{t-1}).

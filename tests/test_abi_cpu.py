@@ -55,8 +55,8 @@ def test_integration_md_declares_the_structs_the_library_has(lib):
     sizes = (ctypes.c_size_t * 3)()
     lib.dcv_abi_struct_sizes(sizes)
     assert tuple(sizes) == (ctypes.sizeof(native.Dims5), ctypes.sizeof(native.ConvGeom), ctypes.sizeof(native.WPack))
-    assert lib.dcv_version() == native.ABI_VERSION == 3
-    assert re.search(r"lib\.dcv_version\(\) == 3", text)
+    assert lib.dcv_version() == native.ABI_VERSION == 4
+    assert re.search(r"lib\.dcv_version\(\) == 4", text)
 
 
 def test_version_and_error_channel(lib):

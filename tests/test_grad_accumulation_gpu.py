@@ -117,3 +117,40 @@ def test_no_torch_add_for_parameter_gradients():
     with_own, without = adds(True), adds(False)
     # what remains are the activation-gradient fan-ins of the trainer's own graph (the fake clips feed three discriminators) and the loss sums
     assert with_own <= without - 50, (with_own, without)
+
+
+@pytest.mark.parametrize("config,cl", [("isogd-depth", False), ("surreal-depth1", False), ("surreal-depth1", True)], ids=["isogd-depth", "surreal-depth1", "surreal-depth1-bf16cl"])
+def test_no_torch_compute_kernel_in_the_iteration(config, cl):
+    """one iteration of StepRunner (fp32 path; adversarial and hinge loss, the latter with the gradient discriminator outside the G loss)
+    launches no torch compute kernel at all — the loss sums (ops.gan_loss_sum, ops.sum_scalars), the cotangent scaling (dcv_scale_dev), the fake clips' fan-in
+    (ops.fan_out), the tiled latents (ops.tile_rows) and the backward roots are the library's; what torch still does is memory copies (the loss mirrors)."""
+    from torch.profiler import ProfilerActivity, profile
+    from dcvgan_amd import trainer
+    from dcvgan_amd.configs import CONFIGS
+    from dcvgan_amd.rng import PhiloxRng
+    from dcvgan_amd import ops_cl
+    dev = torch.device("cuda:0")
+    cfg = CONFIGS[config].scaled(batchsize=2, width_div=4)
+    torch.manual_seed(1)
+    ops_cl.enable(cl)
+    try:
+        models = trainer.build_models(cfg, dev)
+        r = PhiloxRng(5)
+        for m in models.values():
+            m._rng = r
+        xc = torch.rand(2, 3, 16, 64, 64, device=dev) * 2 - 1; xg = torch.rand(2, cfg.channel, 16, 64, 64, device=dev) * 2 - 1
+        runner = trainer.StepRunner(cfg, models, trainer.build_optimizers(cfg, models), trainer.build_loss(cfg), sync_losses=False)
+        for t in (1, 2):      # both parities of the update gating (surreal-depth1: the D phase's backward every second iteration), Adam state exists
+            runner.step(xc, xg, t)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            runner.step(xc, xg, 3)
+            runner.step(xc, xg, 4)
+            torch.cuda.synchronize()
+    finally:
+        ops_cl.enable(False)
+    from torch.autograd import DeviceType
+    kernels = {e.key: e.count for e in prof.key_averages() if e.device_type == DeviceType.CUDA}
+    foreign = {k[:160]: n for k, n in kernels.items() if "at::" in k or "torch" in k.lower()}
+    assert not foreign, foreign
+    assert any("gan_loss" in k for k in kernels) and any("scale_dev" in k for k in kernels) and any(("cl_gather" if cl else "gather_gemm") in k for k in kernels), sorted(kernels)[:40]
