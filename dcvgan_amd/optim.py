@@ -141,6 +141,7 @@ class GradBucket:
         self._flat: Optional[torch.Tensor] = None
         self._chunks = []         # _Chunk objects: element ranges of the buffer, one collective each
         self._comm = None
+        self.timed = None         # a list: (start event, end event, bytes) of every collective launched from reduce() (bench.py's per-phase collective time)
 
     class _Chunk:
         __slots__ = ("a", "b", "members", "record", "arrived", "events", "work", "task", "fresh")
@@ -168,7 +169,8 @@ class GradBucket:
         self._chunks = []
         cur_a, cur_members = 0, []
         for (a, b, members) in spans:
-            if cur_members and ((b - cur_a) * 4 > self.bucket_bytes or ((cur_members[-1]._dcv_grad_off + 1 - cur_a) * 4 >= self.merge_bytes and (b - a) * 4 >= self.merge_bytes)):
+            cur_end = cur_members[-1]._dcv_grad_off + (cur_members[-1].numel() + 63) // 64 * 64 if cur_members else cur_a      # one past the open chunk's last member
+            if cur_members and ((b - cur_a) * 4 > self.bucket_bytes or ((cur_end - cur_a) * 4 >= self.merge_bytes and (b - a) * 4 >= self.merge_bytes)):
                 self._chunks.append(GradBucket._Chunk(cur_a, a, cur_members))
                 cur_a, cur_members = a, []
             for p in members:
@@ -256,8 +258,13 @@ class GradBucket:
                     c.work = self.dist.all_reduce(flat[c.a:c.b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
                 flat.record_stream(self._comm)
             else:
+                if self.timed is not None:      # bench.py: HIP events around the collective as the compute stream sees it (issue ... data reduced)
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record(cur)
                 c.work = self.dist.all_reduce(flat[c.a:c.b], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-                _ = cur
+                if self.timed is not None:
+                    c.work.wait()
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record(cur)
+                    self.timed.append((e0, e1, (c.b - c.a) * 4))
         else:
             self.dist.all_reduce(flat[c.a:c.b], op=self.dist.ReduceOp.SUM, group=self.group)
             c.work = True                        # CPU (gloo rehearsal): done on return

@@ -1,6 +1,8 @@
 """Child process of tests/test_dp_gpu.py: one data-parallel rank driving the REAL DCVGAN modules (width / 8) through
 trainer.StepRunner + optim.DataParallelAdam on cuda:0, gloo collectives (two ranks may share one card; RCCL refuses
-that).  Usage: python tests/dp_worker.py RANK WORLD PORT MODE OUT.json      MODE: "distinct" | "same" | "same-cl16" (the bf16 channels-last data path) """
+that).  Usage: python tests/dp_worker.py RANK WORLD PORT MODE OUT.json
+MODE: "distinct" | "same" | "same-cl16" (the bf16 channels-last data path) | "same-overlap" | "distinct-overlap" (GradBucket(overlap=True): chunked collectives launched
+from the gradient hooks; three iterations — the arrival order is learned in the first backward — and, for distinct data, a twin reduced the plain way to compare with) """
 import copy
 import json
 import os
@@ -20,6 +22,9 @@ def main():
     from dcvgan_amd import ops_cl, optim, trainer
     from dcvgan_amd.configs import CONFIGS
     wdiv = 8
+    overlap = mode.endswith("-overlap")
+    if overlap:
+        mode = mode[:-8]
     if mode.endswith("-cl16"):
         ops_cl.enable(True)
         mode = mode[:-5]
@@ -33,8 +38,9 @@ def main():
     for m in models.values():
         optim.broadcast_module(m)                              # ... made identical here
     solo = copy.deepcopy(models) if mode == "same" else None   # a world-1 twin (plain Adam) for the exactness check
+    plain = copy.deepcopy(models) if (overlap and mode == "distinct") else None      # a twin reduced without overlap
     p_init = torch.cat([p.detach().reshape(-1) for m in models.values() for p in m.parameters()]).cpu()
-    opts = trainer.build_optimizers(cfg, models, data_parallel=True)
+    opts = trainer.build_optimizers(cfg, models, data_parallel=True, overlap=overlap)
     buckets = {id(o.bucket): o.bucket for o in opts.values()}
     assert len(buckets) == 2, "one bucket per phase"
     seed = cfg.seed + (0 if mode == "same" else rank)
@@ -49,7 +55,7 @@ def main():
 
     # capture local gradients right before each reduction, and the reduced ones right after
     captured = []
-    for b in buckets.values():
+    for b in ([] if overlap else buckets.values()):      # (with overlap a chunk may already be reduced when reduce() is called: checked through the twins below instead)
         orig = b.reduce
 
         def wrapped(b=b, orig=orig):
@@ -64,7 +70,8 @@ def main():
     with_rng(models, 1000 + seed)
     runner = trainer.StepRunner(cfg, models, opts, trainer.build_loss(cfg))
     n_coll = []
-    for it in range(2):
+    n_it = 3 if overlap else 2
+    for it in range(n_it):
         c0 = sum(b.collectives for b in buckets.values())
         runner.step(xc, xg, 3 + it)
         n_coll.append(sum(b.collectives for b in buckets.values()) - c0)
@@ -94,12 +101,23 @@ def main():
     if solo is not None:
         with_rng(solo, 1000 + seed)
         r2 = trainer.StepRunner(cfg, solo, trainer.build_optimizers(cfg, solo), trainer.build_loss(cfg))
-        for it in range(2):
+        for it in range(n_it):
             r2.step(xc, xg, 3 + it)
         torch.cuda.synchronize()
         ps = torch.cat([p.detach().reshape(-1) for m in solo.values() for p in m.parameters()]).cpu()
         res["equals_single_process"] = bool((ps == params).all())
         res["moved"] = float((ps != p_init).float().mean()) > 0.9   # an optimiser that never stepped would also be "identical"
+    if overlap:
+        res["early_collectives"] = sum(b.early for b in buckets.values())
+    if plain is not None:      # distinct data: the overlapped reduction against the plain one, same collectives on the same ranges -> the same bits
+        with_rng(plain, 1000 + seed)
+        r3 = trainer.StepRunner(cfg, plain, trainer.build_optimizers(cfg, plain, data_parallel=True, overlap=False), trainer.build_loss(cfg))
+        for it in range(n_it):
+            r3.step(xc, xg, 3 + it)
+        torch.cuda.synchronize()
+        pp = torch.cat([p.detach().reshape(-1) for m in plain.values() for p in m.parameters()]).cpu()
+        res["equals_plain_reduction"] = bool((pp == params).all())
+        res["moved"] = float((pp != p_init).float().mean()) > 0.9
     json.dump(res, open(out, "w"))
     dist.destroy_process_group()
 
