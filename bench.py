@@ -607,6 +607,7 @@ def main():
                          "step": {"achieved": step_tflops, "frac": step_tflops / peak, "flops_per_video_step": f_step},
                          "hbm": {"algorithmic_gb_per_step": gb_step, "achieved_gbps": gb_step / per_step, "peak_gbps": PEAK_HBM_GBPS,
                                  "frac": gb_step / per_step / PEAK_HBM_GBPS}},
+            "env_toggles": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DCV_")} or None,      # every A/B switch that was set for this run (none in the driver's)
             "cpu_baseline": cpu,
             "data_parallel": dp_info,
             "minimal_schedule": minimal,

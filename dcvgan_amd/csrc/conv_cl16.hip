@@ -2200,7 +2200,11 @@ static int cl_conv_run(int which, const dcv_conv_geom* g, const void* src_p, con
             if (pitch) *pitch = OCp;
         }
     }
-    static const int dbg = getenv("DCV_CL_DEBUG") ? atoi(getenv("DCV_CL_DEBUG")) : 0;      // 1: no epilogue stores (timing experiments only)
+#ifdef DCV_DEBUG_TIMING      // timing-experiment builds only: the shipped library cannot be told to drop its stores
+    static const int dbg = getenv("DCV_CL_DEBUG") ? atoi(getenv("DCV_CL_DEBUG")) : 0;      // 1: no epilogue stores
+#else
+    constexpr int dbg = 0;
+#endif
     for (int i = 0; i < n; ++i) pk.c[i].pad2 = dbg;
     ClSplitK sk = {0, 0, 0, 0};
     if (!stat && !accumulate && !gate) sk = cl_splitk_plan(n, thin, pk.c[0].M, (int)pk.c[0].div_sp.div, OCp, pk.c[0].nsteps, tc, ocs);

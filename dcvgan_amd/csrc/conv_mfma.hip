@@ -2703,8 +2703,10 @@ static int flush_packs(const float* w, const PackArgs& packs, int n, int kmax, i
 }
 
 static int flush_pending(GatherArgsPack& pend, int n, dim3 grid, const TileCfg& tc, int KS, int OC, hipStream_t stream) {
+#ifdef DCV_DEBUG_TIMING      // timing-experiment builds only (EXTRA_HIPCC_FLAGS=-DDCV_DEBUG_TIMING into an alt library): the shipped library cannot be told to drop its stores
     static const bool nostore = getenv("DCV_DEBUG_NOSTORE") != nullptr;
     if (nostore) for (int i = 0; i < n; ++i) pend.c[i].p_pad2 = 0x5701;
+#endif
     for (int i = n; i < 4; ++i) pend.c[i] = pend.c[0];
     {   // grid.x comes in as the largest class's (oc tiles x position tiles); see the kernel's id -> tile mapping
         const unsigned tiles_oc = (unsigned)(pend.c[0].OCp / tc.bn);

@@ -238,6 +238,7 @@ class _ActCl(Function):
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
+        _req(y, "activation backward: the saved output (element type switched since the forward?)")
         act, slope = ctx.cfg
         return _ew(3 if act == ACT_LEAKY else 4, as_cl(dy), y, slope), None, None
 
@@ -316,6 +317,7 @@ class _ConvCl(Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
+        _req(x, "conv backward: the saved input (ops_cl.enable(half=...) was switched between this layer's forward and its backward?)")
         g = ctx.g
         L = lib()
         dy = as_cl(dy)
@@ -443,6 +445,7 @@ class _BnActCl(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats, mask = ctx.saved_tensors
+        _req(x, "BatchNorm backward: the saved input (ops_cl.enable(half=...) was switched between this layer's forward and its backward?)")
         training, act, slope = ctx.cfg
         L = lib()
         dy = as_cl(dy)
