@@ -50,6 +50,16 @@ std::atomic<int> g_precision{0};
 static thread_local int t_precision = -1;
 // dcv_conv_backward_weight_acc: the slab reduce of the calling thread's weight-gradient call ADDS its sum to dw (set around the call, read at the three reduce launches)
 static thread_local int t_wgrad_acc = 0;
+// dcv_conv_backward_data_bn's request to the data-gradient path: when the op is the colour generator's RGB head (widen_mfma_kernel's geometry), run_gather launches
+// head_bn_kernel<mode> instead and sets `used`
+struct HeadBnRequest {
+    int mode, used, nwg;
+    const float* bx; dcv_dims5 bxd; float* bdx; dcv_dims5 bdxd;
+    const float* gamma; const float* beta; const float* mean; const float* invstd;
+    const float* cst; float* partial; size_t partial_bytes;
+    int cbn; float slope;
+};
+static thread_local HeadBnRequest* t_headbn = nullptr;
 static inline int eff_precision() { return t_precision >= 0 ? t_precision : g_precision.load(std::memory_order_relaxed); }
 struct PrecisionScope {
     int saved;
@@ -1563,6 +1573,214 @@ __global__ __launch_bounds__(256, 4) void widen_mfma_kernel(const GatherArgs a, 
 #pragma unroll
             for (int m = 0; m < KS; ++m) bcur[m] = bnxt[m];
         }
+    }
+}
+
+// --------------------------------------------------------------------------- //
+// head_bn_kernel (round 6): widen_mfma_kernel<3, 4> fused with the backward of the BatchNorm + (Leaky)ReLU that produced the head's first `cbn` input channels —
+// the last stage of the colour generator: UpBlock 5's BatchNorm -> concat with the stem's skip -> Outconv (generator.py:238-282,393-400).  Unfused, the head's data
+// gradient WRITES 2.35 GB, BatchNorm's reduction reads half of it back with the BatchNorm input (2.35 GB) and its apply pass reads both again and writes 1.17 GB:
+// 8.2 GB per backward.  A tile of that gradient is 14 MFMAs away from the 3-channel cotangent, so the first half never has to exist in memory:
+//   MODE 1  recomputes every tile; for the BatchNorm channels it loads the matching tile of the BatchNorm INPUT (same register layout as the stores: 128-byte
+//           runs of a channel row), forms dz = dx * act'(z) with z = x * sc + sh exactly as the forward did, and accumulates sum dz and sum dz (x - mean) per
+//           channel (lanes by DPP, waves through LDS, one partial row per workgroup); the other channels' tiles are stored as before;
+//   MODE 2  (after the finalize) recomputes the BatchNorm channels' tiles once more and writes the gradient of the BatchNorm INPUT directly:
+//           sc dz + c0 + c1 (x - mean), c0 = -sc sum(dz) / n, c1 = -sc invstd^2 sum(dz (x - mean)) / n.
+// 4.7 GB instead of 8.2 GB, two launches + a finalize instead of widen + reduce + finalize + apply.
+// --------------------------------------------------------------------------- //
+struct HeadBnArgs {
+    GatherArgs g;
+    const float* bx;                 // BatchNorm input (cbn channels, the head's spatial size)
+    float* bdx;                      // MODE 2: its gradient
+    const float* gamma; const float* beta; const float* mean; const float* invstd;
+    const float* cst;                // MODE 2: [cbn][2] = {c0, c1}
+    float* partial;                  // MODE 1: [workgroups][cbn][2]
+    int64_t bx_sn, bdx_sn;
+    int32_t bx_sc, bx_sh, bx_sw, bdx_sc, bdx_sh, bdx_sw;
+    int32_t cbn, groups;
+    float slope; int32_t pad;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void head_bn_kernel(const HeadBnArgs h) {
+    constexpr int RC = 3, MT = 4, K = RC * 9, KS = (K + 1) / 2;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ float wl[2 * KS][MT * 32];
+    __shared__ f32x4 c4[MT * 32];            // per BatchNorm channel: sc = gamma * invstd, sh = beta - mean * sc, mean, (unused)
+    __shared__ f32x2 c2[MT * 32];            // MODE 2: c0, c1
+    __shared__ float red[4][MT * 32][2];     // MODE 1: per-wave channel sums
+    const GatherArgs& a = h.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int cbn = h.cbn, MB = cbn >> 5;      // BatchNorm channel tiles
+    for (int e = tid; e < 2 * KS * MT * 32; e += 256) {
+        const int k = e / (MT * 32), oc = e - k * (MT * 32);
+        const int rc = k / 9, t = k - rc * 9;
+        int pt = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pt = (t == q) ? a.s_local[q] : pt;
+        wl[k][oc] = (k < K && oc < a.OCp) ? a.wp[(int64_t)(rc * 9 + pt) * a.OCp + oc] : 0.f;
+    }
+    if (tid < cbn) {
+        const float is = h.invstd[tid], mu = h.mean[tid];
+        const float sc = h.gamma[tid] * is, sh = h.beta[tid] - mu * sc;      // BnApply's own expressions: the branch of the activation must be the forward's
+        c4[tid] = f32x4{sc, sh, mu, 0.f};
+        if (MODE == 2) c2[tid] = f32x2{h.cst[2 * tid], h.cst[2 * tid + 1]};
+    }
+    if (MODE == 1)
+        for (int e = tid; e < 4 * MT * 32 * 2; e += 256) (&red[0][0][0])[e] = 0.f;
+    const int groups = h.groups;
+    const uint32_t gpp = ((uint32_t)a.OH >> 2) / (uint32_t)groups;
+    uint32_t plane, gb;
+    xcd_plane_map(blockIdx.x, gpp, gridDim.x, plane, gb);
+    const uint32_t n = plane / (uint32_t)a.OD, od = plane - n * (uint32_t)a.OD;
+    int32_t kb4[KS];
+    uint32_t padmask = 0, b0mask = 0, b2mask = 0, r0mask = 0, r1mask = 0, r2mask = 0;
+#pragma unroll
+    for (int m = 0; m < KS; ++m) {
+        const int k = 2 * m + lhi;
+        const bool live = k < K;
+        const int kk = live ? k : 0;
+        const int rc = kk / 9, t = kk - rc * 9, ra = t / 3, b = t - ra * 3;
+        kb4[m] = rc * a.s_stepA + 4 * (ra * a.x_sh + b);
+        padmask |= live ? 0u : 1u << m;
+        b0mask |= (live && b == 0) ? 1u << m : 0u;
+        b2mask |= (live && b == 2) ? 1u << m : 0u;
+        r0mask |= (live && ra == 0) ? 1u << m : 0u;
+        r1mask |= (live && ra == 1) ? 1u << m : 0u;
+        r2mask |= (live && ra == 2) ? 1u << m : 0u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x + (int64_t)n * a.x_sn + (int64_t)((int)od * a.td.mul + a.td.base + a.td.delta[0]) * a.x_sd), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y + a.y_off + (int64_t)n * a.y_sn + (int64_t)od * a.y_sd, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(h.bx + (int64_t)n * h.bx_sn), 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bdrs = __builtin_amdgcn_make_buffer_rsrc((MODE == 2 ? h.bdx : a.y) + (MODE == 2 ? (int64_t)n * h.bdx_sn : 0), 0, 0x80000000u, 0x00020000);
+    const int ysh = (int)a.y_sh, ysw = (int)a.y_sw;
+    const uint32_t ysc4 = (uint32_t)a.y_sc * 4u, bxsc4 = (uint32_t)h.bx_sc * 4u, bdsc4 = (uint32_t)h.bdx_sc * 4u;
+    const float slope = h.slope;
+
+    auto load_b = [&](int oh, int x0, float (&bv)[KS]) {
+        const int ih0 = oh + a.p_ihmin;
+        const int col = x0 + l31;
+        uint32_t bad = padmask | (col == 0 ? b0mask : 0u) | (col == a.tw.size - 1 ? b2mask : 0u);
+        if ((unsigned)ih0 >= (unsigned)a.th.size) bad |= r0mask;
+        if ((unsigned)(ih0 + 1) >= (unsigned)a.th.size) bad |= r1mask;
+        if ((unsigned)(ih0 + 2) >= (unsigned)a.th.size) bad |= r2mask;
+        const int base4 = 4 * (ih0 * a.x_sh + col - 1);
+#pragma unroll
+        for (int m = 0; m < KS; ++m) {
+            const uint32_t vo = ((bad >> m) & 1u) ? 0x80000000u : (uint32_t)(base4 + kb4[m]);
+            bv[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vo, 0, 0));
+        }
+    };
+
+    const int ntile = groups * 2;
+    __syncthreads();
+    const int ohw = (int)gb * groups * 4 + wave * groups;
+    const int mt_end = MODE == 2 ? MB : MT;
+#pragma unroll 1
+    for (int mt = 0; mt < mt_end; ++mt) {
+        const bool bn = mt < MB;               // wave-uniform
+        float af[KS];
+#pragma unroll
+        for (int m = 0; m < KS; ++m) af[m] = wl[2 * m + lhi][mt * 32 + l31];
+        float s1[16], s2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+        float bcur[KS], bnxt[KS];
+        load_b(ohw, 0, bcur);
+#pragma unroll 1
+        for (int tt = 0; tt < ntile; ++tt) {
+            const int oh = ohw + (tt >> 1), x0 = (tt & 1) * 32;
+            // the BatchNorm input's tile, in the accumulators' layout, issued ahead of the MFMAs that hide its latency
+            float xt[16];
+            if (bn) {
+                const uint32_t xv = (uint32_t)(4 * (oh * h.bx_sh + (x0 + l31) * h.bx_sw)) + (uint32_t)(4 * lhi) * bxsc4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    xt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxrs, xv, (uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * bxsc4, 0));
+            }
+            if (tt + 1 < ntile) load_b(ohw + ((tt + 1) >> 1), ((tt + 1) & 1) * 32, bnxt);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < KS; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bcur[m], acc, 0, 0, 0);
+            if (bn) {
+                const uint32_t dv = (uint32_t)(4 * (oh * h.bdx_sh + (x0 + l31) * h.bdx_sw)) + (uint32_t)(4 * lhi) * bdsc4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    const f32x4 k4 = c4[ch];
+                    const float z = xt[r] * k4[0] + k4[1];
+                    const float dz = acc[r] * (z > 0.f ? 1.f : slope);
+                    const float xm = xt[r] - k4[2];
+                    if (MODE == 1) {
+                        s1[r] += dz;
+                        s2[r] += dz * xm;
+                    } else {
+                        const f32x2 k2 = c2[ch];
+                        const float o = k4[0] * dz + k2[0] + k2[1] * xm;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), bdrs, dv, (uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * bdsc4, 2);
+                    }
+                }
+            } else {
+                const uint32_t yv = (uint32_t)(4 * (oh * ysh + (x0 + l31) * ysw)) + (uint32_t)(4 * lhi) * ysc4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[r];      // (a copy: __builtin_bit_cast applied to the vector ELEMENT expression itself compiled to element 0 for every r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), yrs, yv, (uint32_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * ysc4, 2);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < KS; ++m) bcur[m] = bnxt[m];
+        }
+        if (MODE == 1 && bn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float t1 = half_wave_sum(s1[r]), t2 = half_wave_sum(s2[r]);
+                if (l31 == 31) {
+                    const int ch = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    red[wave][ch][0] = t1;
+                    red[wave][ch][1] = t2;
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        if (tid < 2 * cbn) {
+            const int ch = tid >> 1, w = tid & 1;
+            h.partial[((int64_t)blockIdx.x * cbn + ch) * 2 + w] = ((red[0][ch][w] + red[1][ch][w]) + red[2][ch][w]) + red[3][ch][w];
+        }
+    }
+}
+
+// partial[workgroups][cbn][2] -> dbeta = sum dz, dgamma = invstd sum dz (x - mean); cst[cbn][2] for head_bn_kernel<2>.  One workgroup per channel, fp64, fixed order.
+__global__ __launch_bounds__(256) void head_bn_finalize_kernel(const float* __restrict__ partial, int nwg, int cbn, double count, const float* __restrict__ gamma,
+                                                               const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ cst) {
+    __shared__ double red[2][256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int w = tid; w < nwg; w += 256) {
+        a0 += (double)partial[((int64_t)w * cbn + c) * 2];
+        a1 += (double)partial[((int64_t)w * cbn + c) * 2 + 1];
+    }
+    red[0][tid] = a0; red[1][tid] = a1;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double is = (double)invstd[c], sc = (double)gamma[c] * is;
+        const double S1 = red[0][0], S2 = red[1][0];
+        dbeta[c] = (float)S1;
+        dgamma[c] = (float)(S2 * is);
+        cst[2 * c] = (float)(-sc * S1 / count);
+        cst[2 * c + 1] = (float)(-sc * is * is * S2 / count);
     }
 }
 
@@ -3249,6 +3467,32 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                     const int OHc = c.o_ext[1];
                     const int groups = OHc % 16 == 0 ? 4 : OHc % 8 == 0 ? 2 : 1;   // rows per wave (measured 1 / 2 / 4 / 8 / 16 at B = 70: 0.57 / 0.53 / 0.53 / 0.70 / 0.80 ms)
                     const dim3 gm((unsigned)(M64 / 256 / groups));
+                    if (HeadBnRequest* hb = t_headbn) {      // fused with the BatchNorm backward of the first hb->cbn channels (dcv_conv_backward_data_bn)
+                        const bool ok = OCp == 128 && OC == 128 && (hb->cbn == 32 || hb->cbn == 64 || hb->cbn == 96) && !accumulate && act == DCV_ACT_NONE && c.o_ext[0] == 1 &&
+                                        hb->bxd.n == yd.n && hb->bxd.c == hb->cbn && hb->bxd.d == 1 && hb->bxd.h == OHc && hb->bxd.w == 64 &&
+                                        hb->bxd.sn >= 0 && hb->bxd.sc >= 0 && hb->bxd.sh >= 0 && hb->bxd.sw >= 0 &&
+                                        (int64_t)hb->cbn * hb->bxd.sc + (int64_t)OHc * hb->bxd.sh + 64 * hb->bxd.sw < (1ll << 29) &&
+                                        (hb->mode == 1 ? (size_t)gm.x * hb->cbn * 2 * sizeof(float) <= hb->partial_bytes
+                                                       : (hb->bdxd.sn >= 0 && hb->bdxd.sc >= 0 && hb->bdxd.sh >= 0 && hb->bdxd.sw >= 0 &&
+                                                          (int64_t)hb->cbn * hb->bdxd.sc + (int64_t)OHc * hb->bdxd.sh + 64 * hb->bdxd.sw < (1ll << 29)));
+                        if (ok) {
+                            HeadBnArgs ha;
+                            memset(&ha, 0, sizeof(ha));
+                            ha.g = a;
+                            ha.bx = hb->bx; ha.bdx = hb->bdx; ha.gamma = hb->gamma; ha.beta = hb->beta; ha.mean = hb->mean; ha.invstd = hb->invstd;
+                            ha.cst = hb->cst; ha.partial = hb->partial;
+                            ha.bx_sn = hb->bxd.sn; ha.bx_sc = (int32_t)hb->bxd.sc; ha.bx_sh = (int32_t)hb->bxd.sh; ha.bx_sw = (int32_t)hb->bxd.sw;
+                            ha.bdx_sn = hb->bdxd.sn; ha.bdx_sc = (int32_t)hb->bdxd.sc; ha.bdx_sh = (int32_t)hb->bdxd.sh; ha.bdx_sw = (int32_t)hb->bdxd.sw;
+                            ha.cbn = hb->cbn; ha.groups = groups; ha.slope = hb->slope;
+                            DCV_NOTE_KERNEL("head_bn_kernel<%d> (RGB head data gradient + BatchNorm backward of %d channels)", hb->mode, hb->cbn);
+                            if (hb->mode == 1) hipLaunchKernelGGL((head_bn_kernel<1>), gm, dim3(256), 0, stream, ha);
+                            else hipLaunchKernelGGL((head_bn_kernel<2>), gm, dim3(256), 0, stream, ha);
+                            DCV_LAUNCH_CHECK();
+                            hb->used = 1;
+                            hb->nwg = (int)gm.x;
+                            continue;
+                        }
+                    }
                     DCV_NOTE_KERNEL("widen_mfma_kernel<%d, %d>", RC, OCp / 32);
                     if (OCp == 128) hipLaunchKernelGGL((widen_mfma_kernel<3, 4>), gm, dim3(256), 0, stream, a, groups);
                     else hipLaunchKernelGGL((widen_mfma_kernel<3, 2>), gm, dim3(256), 0, stream, a, groups);
@@ -3946,6 +4190,53 @@ size_t dcv_conv_workspace_bytes(const dcv_conv_geom* g, const dcv_dims5* x, cons
     }
     if (conv_dispatch(which, g, nullptr, x, nullptr, nullptr, y, 0, 0.f, 0, nullptr, 0, nullptr, &need) != DCV_OK) return 0;
     return need;
+}
+
+size_t dcv_conv_backward_data_bn_workspace_bytes(const dcv_dims5* dx, int cbn) {
+    if (!dx || cbn < 1) return 0;
+    // one partial row per workgroup (at most one per 4 output rows of a plane) + the finalize's constants
+    return align_up((size_t)dx->n * dx->d * ((dx->h + 3) / 4) * cbn * 2 * sizeof(float), 256) + align_up((size_t)cbn * 2 * sizeof(float), 256) + 256;
+}
+
+int dcv_conv_backward_data_bn(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd, const dcv_wpack* pack,
+                              void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, int act, float slope, float* bn_dx, const dcv_dims5* bn_dxd, float* dgamma, float* dbeta,
+                              void* ws2, size_t ws2_bytes, int* fused, void* stream) {
+    if (!fused || !bn_x || !bn_xd || !gamma || !beta || !save_mean || !save_invstd || !bn_dx || !bn_dxd || !dgamma || !dbeta || !dxd || !ws2)
+        return fail(DCV_EINVAL, "conv_backward_data_bn: null pointer");
+    *fused = 0;
+    if (act != DCV_ACT_NONE && act != DCV_ACT_LEAKY) return fail(DCV_EUNSUPPORTED, "conv_backward_data_bn: the BatchNorm's activation must be none or (Leaky)ReLU");
+    if (eff_precision() != 0 && !(g && g->mfma == 1)) return fail(DCV_EUNSUPPORTED, "conv_backward_data_bn: fp32 path only");
+    const size_t pbytes = align_up((size_t)dxd->n * dxd->d * ((dxd->h + 3) / 4) * cbn * 2 * sizeof(float), 256);
+    if (ws2_bytes < dcv_conv_backward_data_bn_workspace_bytes(dxd, cbn)) return fail(DCV_EWORKSPACE, "conv_backward_data_bn: second workspace too small");
+    HeadBnRequest hb;
+    memset(&hb, 0, sizeof(hb));
+    hb.mode = 1;
+    hb.bx = bn_x; hb.bxd = *bn_xd; hb.bdx = bn_dx; hb.bdxd = *bn_dxd;
+    hb.gamma = gamma; hb.beta = beta; hb.mean = save_mean; hb.invstd = save_invstd;
+    hb.partial = static_cast<float*>(ws2); hb.partial_bytes = pbytes;
+    float* cst = reinterpret_cast<float*>(static_cast<char*>(ws2) + pbytes);
+    hb.cst = cst;
+    hb.cbn = cbn; hb.slope = act == DCV_ACT_LEAKY ? slope : 1.f;
+    t_headbn = &hb;
+    int rc = conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, 0, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pack);
+    t_headbn = nullptr;
+    if (rc != DCV_OK || !hb.used) return rc;      // not the head's geometry: the plain data gradient ran, dx is complete, *fused stays 0
+    const double count = (double)bn_xd->n * bn_xd->d * bn_xd->h * bn_xd->w;
+    hipLaunchKernelGGL(head_bn_finalize_kernel, dim3(cbn), dim3(256), 0, static_cast<hipStream_t>(stream), hb.partial, hb.nwg, cbn, count, gamma, save_invstd, dgamma, dbeta, cst);
+    DCV_LAUNCH_CHECK();
+    hb.mode = 2;
+    hb.used = 0;
+    dcv_wpack pk2;
+    const dcv_wpack* pk2p = nullptr;
+    if (pack && pack->buf) { pk2 = *pack; pk2.ready = 1; pk2p = &pk2; }      // the first call packed the weights
+    t_headbn = &hb;
+    rc = conv_dispatch(1, g, dy, dxd, w, dx, dyd, DCV_ACT_NONE, 0.f, 0, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pk2p);
+    t_headbn = nullptr;
+    if (rc != DCV_OK) return rc;
+    if (!hb.used) return fail(DCV_EINVAL, "conv_backward_data_bn: internal: the second pass did not take the fused kernel");
+    *fused = 1;
+    return DCV_OK;
 }
 
 size_t dcv_conv_packed_bytes(const dcv_conv_geom* g, const dcv_dims5* x, const dcv_dims5* y, int which) {

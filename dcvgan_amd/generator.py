@@ -136,8 +136,8 @@ class Outconv(nn.Module):
         self.main = nn.Sequential(_convT(in_ch, out_ch, 3, 1, 1), nn.Tanh())
 
 
-def _block_forward(self, x, rng=None, out=None, grad_slot=None, act_slot=None):
-    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out, grad_slot=grad_slot, act_slot=act_slot)
+def _block_forward(self, x, rng=None, out=None, grad_slot=None, act_slot=None, bn_link=None):
+    return layers.run(self.main, x, rng if rng is not None else default_rng(), out=out, grad_slot=grad_slot, act_slot=act_slot, bn_link=bn_link)
 
 
 for _cls in (Inconv, DownBlock, UpBlock, Outconv):
@@ -190,10 +190,13 @@ class ColorVideoGenerator(nn.Module):
             skips.append(blk(skips[-1], rng, out=dst, grad_slot=bufs[k].slot))   # skips[k] lives in bufs[k].second
         zc = ops.copy_into(z, bufs[6].second)
         h = bufs[6].join(skips[6], zc)
+        # the last stage — UpBlock 5's BatchNorm -> cat with the stem's skip -> Outconv — shares an ops.BnLink: in the backward the head's data gradient and that
+        # BatchNorm's backward run as one fused pair of launches (dcv_conv_backward_data_bn)
+        link = ops.BnLink()
         for i, blk in enumerate(self.up_blocks):
-            h = blk(h, rng, out=bufs[5 - i].first)
+            h = blk(h, rng, out=bufs[5 - i].first, bn_link=link if i == 5 else None)
             h = bufs[5 - i].join(h, skips[5 - i])
-        return self.outconv(h, rng)
+        return self.outconv(h, rng, bn_link=link)
 
     def _forward_cl(self, x, z, rng):
         """The same U-Net on the bf16 channels-last data path: x, z fp32 in, RGB frames fp32 out; every concatenation is two channel ranges of

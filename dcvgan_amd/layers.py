@@ -58,7 +58,7 @@ def geom_of(conv) -> "ops.ConvGeom":
     return ops.conv_geom(conv.weight, conv.stride, conv.padding, isinstance(conv, nn.ConvTranspose2d), getattr(conv, "_dcv_precision", None))
 
 
-def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, partials=None):
+def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, partials=None, link=None):
     training = bn.training
     mask = None
     if dropout is not None and dropout.training:
@@ -70,14 +70,16 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, part
     # num_batches_tracked is bumped by the statistics kernel itself (one launch less per BatchNorm layer)
     return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, act[0], act[1], mask,
                       bn.momentum if bn.momentum is not None else 0.1, bn.eps, out=out, partials=partials if training else None,
-                      num_batches_tracked=bn.num_batches_tracked if training else None)
+                      num_batches_tracked=bn.num_batches_tracked if training else None, link=link)
 
 
-def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_slot=None) -> torch.Tensor:
+def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_slot=None, bn_link=None) -> torch.Tensor:
     """`out`: destination view for the sequence's LAST fused op (a concat-buffer slice), when that
     op is a conv(+act) or a BatchNorm group.  `grad_slot`: ops.GradSlot of the concat buffer that holds x
     (x is a skip tensor): passed to the FIRST convolution, whose data gradient then accumulates into it.
-    `act_slot`: ops.GradSlot of the concat buffer `out` belongs to, for a conv + (Leaky)ReLU that ends the sequence."""
+    `act_slot`: ops.GradSlot of the concat buffer `out` belongs to, for a conv + (Leaky)ReLU that ends the sequence.
+    `bn_link`: ops.BnLink — given to the sequence's LAST BatchNorm group when it ends the sequence (the producer side), and to its FIRST convolution
+    (the consumer side); fp32 path only."""
     layers = list(seq)
     i, n = 0, len(layers)
     pending = None   # BatchNorm partial sums left by the conv that produced x (conv -> BN pairs in training mode)
@@ -99,7 +101,7 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             fused = _act_of(nxt) if nxt is not None else None
             if fused is not None:
                 x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None, grad_slot=grad_slot if i == 0 else None,
-                             act_slot=act_slot if i + 2 >= n else None)
+                             act_slot=act_slot if i + 2 >= n else None, bn_link=bn_link if i == 0 else None)
                 _tap(x, fused)
                 i += 2
             else:
@@ -116,7 +118,8 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             fused = _act_of(layers[j]) if j < n else None
             if fused is not None:
                 j += 1
-            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop, out=out if j >= n else None, partials=pending)
+            x = batch_norm(layer, x, rng, fused or (ops.ACT_NONE, 0.0), drop, out=out if j >= n else None, partials=pending,
+                           link=bn_link if (j >= n and not ops_cl.is_cl(x)) else None)
             _tap(x, fused)
             pending = None
             i = j

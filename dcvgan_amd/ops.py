@@ -292,15 +292,32 @@ def wgrad_join_at_end(device, cur, side) -> None:
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
+class BnLink:
+    """Ties the BatchNorm group that writes the FIRST channels of a concat buffer to the convolution that reads the buffer (the colour generator's last stage:
+    UpBlock 5 -> cat with the stem's skip -> Outconv): `bn_act(..., link=)` notes what its backward needs, `conv(..., bn_link=)`'s backward then runs
+    dcv_conv_backward_data_bn — the data gradient fused with that BatchNorm's backward — and leaves the BatchNorm's results here; the BatchNorm node of the SAME
+    backward pass picks them up instead of reading its cotangent (whose memory the fused kernels never wrote).  Anything the fused entry point does not take
+    (another geometry, eval mode, a dropout mask, the 16-bit path) leaves the link empty and both nodes run as they always did.  DCV_NO_HEAD_BN_FUSION=1: off (A/B)."""
+    __slots__ = ("x", "gamma", "beta", "stats", "act", "slope", "task", "dx", "dgb", "stream")
+
+    def __init__(self):
+        self.x = self.gamma = self.beta = self.stats = self.dx = self.dgb = None
+        self.act, self.slope, self.task, self.stream = ACT_NONE, 0.0, -1, -1
+
+
+_HEAD_BN_FUSION = os.environ.get("DCV_NO_HEAD_BN_FUSION") is None
+
+
 class _Conv(Function):
     # identity token of the current backward pass: a weight's gradient slot is handed out once per backward (new_backward_epoch() is called by
     # the optimiser wrapper's step(), i.e. between two backwards of the same bucket)
     _epoch = [object()]
 
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None, act_slot=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None, act_slot=None, bn_link=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
         ctx.grad_slot = grad_slot
+        ctx.bn_link = bn_link if _HEAD_BN_FUSION else None
         ctx.act_slot = act_slot if (act_slot is not None and act == ACT_LEAKY) else None
         if ctx.act_slot is not None:
             ctx.act_slot.act, ctx.act_slot.act_applied = (act, slope), False
@@ -363,7 +380,28 @@ class _Conv(Function):
             pk = ctx.pack.get(w, 1, g, dx, dy, dxd, dyd) if ctx.pack is not None else None
             pkp = C.byref(pk) if pk is not None else None
             rc = N.DCV_EUNSUPPORTED
-            if into is not None and slot.act is not None and _GATED_DGRAD and tuple(x.stride()) == tuple(into.stride()):
+            link = ctx.bn_link
+            if link is not None and link.x is not None and into is None and g.transposed and link.x.shape[0] == x.shape[0] and link.x.shape[2:] == x.shape[2:] \
+                    and link.x.shape[1] < x.shape[1] and torch.cuda.current_stream(x.device).cuda_stream == link.stream:      # (the BatchNorm ran on this stream too)
+                # the first channels of x are a BatchNorm group's output: the data gradient fused with that BatchNorm's backward (BnLink)
+                bx = link.x
+                cbn = bx.shape[1]
+                bdx = _empty(bx.shape, bx.device)
+                dgb = _empty((2, cbn), bx.device)
+                bxd, bdxd = dims5(bx), dims5(bdx)
+                need2 = L.dcv_conv_backward_data_bn_workspace_bytes(C.byref(dxd), cbn)
+                ws2p, ws2n = _ws("headbn", need2, x.device)
+                fused = C.c_int(0)
+                rc = L.dcv_conv_backward_data_bn(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), pkp, wsp, wsn, cbn, ptr(bx), C.byref(bxd),
+                                                 ptr(link.gamma), ptr(link.beta), ptr(link.stats[0]), ptr(link.stats[1]), link.act, link.slope,
+                                                 ptr(bdx), C.byref(bdxd), ptr(dgb[0]), ptr(dgb[1]), ws2p, ws2n, C.byref(fused), stream_ptr())
+                if rc == N.DCV_EUNSUPPORTED:
+                    pass                      # (nothing ran: the plain call below)
+                else:
+                    check(rc, "dcv_conv_backward_data_bn")
+                    if fused.value:
+                        link.dx, link.dgb, link.task = bdx, dgb, _task_id()
+            if rc == N.DCV_EUNSUPPORTED and into is not None and slot.act is not None and _GATED_DGRAD and tuple(x.stride()) == tuple(into.stride()):
                 # ... and the derivative of the activation that produced x, read off x, in the same epilogue
                 xd_ = dims5(x)
                 rc = L.dcv_conv_backward_data_gated(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), 1, ptr(x), C.byref(xd_),
@@ -420,7 +458,7 @@ class _Conv(Function):
                 check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
                 if _OWN_ACCUMULATION:
                     note_first(w, dw)
-        return dx, dw, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None
 
 
 def new_backward_epoch():
@@ -428,12 +466,13 @@ def new_backward_epoch():
     _Conv._epoch[0] = object()
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None, act_slot=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None, act_slot=None, bn_link=None):
     """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries.
     `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into.
     `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection), see GradSlot.
-    `act_slot`: ConcatBuffer.slot of the buffer this conv + (Leaky)ReLU writes its output into (`out` is its second slice)."""
-    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot, act_slot)
+    `act_slot`: ConcatBuffer.slot of the buffer this conv + (Leaky)ReLU writes its output into (`out` is its second slice).
+    `bn_link`: the BnLink of the BatchNorm group that produced x's first channels (see BnLink)."""
+    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot, act_slot, bn_link)
 
 
 # --------------------------------------------------------------------------- #
@@ -442,8 +481,9 @@ def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, b
 class _BnAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, mask, training: bool, momentum: float, eps: float, act: int, slope: float, out=None,
-                partials=None, nbt=None):
+                partials=None, nbt=None, link=None):
         N._require(x, "bn input")
+        ctx.link = link
         L = lib()
         Cn = x.shape[1]
         y = _dest(out, x.shape, x.device)
@@ -461,12 +501,26 @@ class _BnAct(Function):
                   "dcv_bn_act_forward")
         ctx.cfg = (bool(training), act, slope)
         ctx.save_for_backward(x, gamma, beta, stats, mask)
+        if link is not None:
+            if training and mask is None and act in (ACT_NONE, ACT_LEAKY) and x.dim() == 4 and x.is_contiguous():
+                link.x, link.gamma, link.beta, link.stats, link.act, link.slope = x, gamma, beta, stats, act, slope
+                link.stream = torch.cuda.current_stream(x.device).cuda_stream
+            else:
+                link.x = None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats, mask = ctx.saved_tensors
         training, act, slope = ctx.cfg
+        link = ctx.link
+        if link is not None and link.dx is not None and link.task == _task_id():
+            # the consumer convolution's backward has already done this node's work (dcv_conv_backward_data_bn); dy's memory was never written
+            dx, dgb = link.dx, link.dgb
+            link.dx = link.dgb = None
+            if _OWN_ACCUMULATION:
+                return (dx, deliver_small(gamma, dgb[0]), deliver_small(beta, dgb[1])) + (None,) * 12
+            return (dx, dgb[0], dgb[1]) + (None,) * 12
         L = lib()
         dy = _dense(dy)
         Cn = x.shape[1]
@@ -478,19 +532,19 @@ class _BnAct(Function):
                                     ptr(stats[0]), ptr(stats[1]), ptr(mask), int(training), act, slope, ptr(dgb[0]), ptr(dgb[1]), wsp, wsn, stream_ptr()),
               "dcv_bn_act_backward")
         if _OWN_ACCUMULATION:
-            return dx, deliver_small(gamma, dgb[0]), deliver_small(beta, dgb[1]), None, None, None, None, None, None, None, None, None, None, None
-        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
+            return (dx, deliver_small(gamma, dgb[0]), deliver_small(beta, dgb[1])) + (None,) * 12
+        return (dx, dgb[0], dgb[1]) + (None,) * 12
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, training: bool, act: int = ACT_NONE, slope: float = 0.0,
-           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None, partials=None, num_batches_tracked=None):
+           mask: Optional[torch.Tensor] = None, momentum: float = 0.1, eps: float = 1e-5, out=None, partials=None, num_batches_tracked=None, link=None):
     """y = act(mask * batch_norm(x)); running stats (and the int64 `num_batches_tracked` buffer, when given) are
     updated in place when training.
     `partials`: (buffer, nparts, pitch) left by the producing conv's epilogue (ops.conv(..., bn_stats=[]))."""
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         raise N.NativeError("bn_act: num_batches_tracked must be an int64 device tensor")
     return _BnAct.apply(x, gamma, beta, running_mean, running_var, mask, training, float(momentum), float(eps), act, float(slope),
-                        None if out is None else _Out(out), None if partials is None else _Opaque(partials), num_batches_tracked)
+                        None if out is None else _Out(out), None if partials is None else _Opaque(partials), num_batches_tracked, link)
 
 
 # --------------------------------------------------------------------------- #

@@ -63,7 +63,7 @@ typedef struct dcv_conv_geom {
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
-/* ABI version.  4 (round 6): dcv_scale_dev exists (no struct changed).  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
+/* ABI version.  4 (round 6): dcv_scale_dev, dcv_conv_backward_data_bn(_workspace_bytes) exist (no struct changed).  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
  * 2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
  * A host compares dcv_version() and dcv_abi_struct_sizes() with its own declarations BEFORE the first call that passes a struct
  * (dcvgan_amd/native.py does, and refuses to load on a mismatch): the library cannot see the size of what a pointer points to. */
@@ -140,6 +140,18 @@ int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const 
                                  float* dx, const dcv_dims5* dxd, int accumulate,
                                  const float* x, const dcv_dims5* xd, int act, float slope, const dcv_wpack* pack,
                                  void* ws, size_t ws_bytes, void* stream);
+/* The data gradient of a convolution whose first `cbn` input channels are the output of a BatchNorm (training mode, no dropout mask) + (Leaky)ReLU | identity, FUSED
+ * with that BatchNorm's backward — the last stage of the colour generator: `UpBlock` 5 -> torch.cat with the stem's skip -> `Outconv`
+ * (generator.py:238-250,272-277,393-400).  Where the geometry is the RGB head's (3x3 / stride 1 / pad 1 transposed, 3 -> 128 channels on 64-wide rows, fp32) the gradient
+ * of those cbn channels is never written: it is recomputed from dy inside the BatchNorm reduction and inside the kernel that writes the gradient of the BatchNorm INPUT
+ * (4.7 GB of HBM traffic per call instead of 8.2 GB at B = 70).  On return *fused = 1: dx[:, cbn:] , bn_dx, dgamma, dbeta are written and dx[:, :cbn] is NOT;
+ * *fused = 0: the plain data gradient ran (any other geometry), dx is complete and the caller runs dcv_bn_act_backward itself.  ws / pack: as dcv_conv_backward_data;
+ * ws2: dcv_conv_backward_data_bn_workspace_bytes(dxd, cbn) bytes.  act: DCV_ACT_NONE or DCV_ACT_LEAKY (slope 0 = ReLU) of the BatchNorm group. */
+size_t dcv_conv_backward_data_bn_workspace_bytes(const dcv_dims5* dxd, int cbn);
+int dcv_conv_backward_data_bn(const dcv_conv_geom* g, const float* dy, const dcv_dims5* dyd, const float* w, float* dx, const dcv_dims5* dxd, const dcv_wpack* pack,
+                              void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, int act, float slope, float* bn_dx, const dcv_dims5* bn_dxd, float* dgamma, float* dbeta,
+                              void* ws2, size_t ws2_bytes, int* fused, void* stream);
 int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd,
                              const float* dy, const dcv_dims5* dyd, float* dw,
                              void* ws, size_t ws_bytes, void* stream);

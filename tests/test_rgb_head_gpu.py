@@ -120,3 +120,49 @@ def test_rgb_head_weight_gradient_accumulates(dev):
     N.check(L.dcv_conv_backward_weight_acc(C.byref(geom), ptr(xd), C.byref(xdm), ptr(dyd_), C.byref(dym), ptr(dwd), 1, ptr(ws), need, stream_ptr()), "wgrad acc")
     assert "thinj_wgrad_kernel" in last_kernel(), last_kernel()
     assert rel(dwd, old + gw) < 2e-5
+
+
+@pytest.mark.parametrize("n,h,cbn,act", [(5, 64, 64, "relu"), (3, 32, 64, "relu"), (2, 16, 32, "leaky"), (9, 8, 96, "none")], ids=lambda v: str(v))
+def test_head_data_gradient_fused_with_the_batchnorm_backward(dev, n, h, cbn, act):
+    """dcv_conv_backward_data_bn against the two calls it replaces (dcv_conv_backward_data, then dcv_bn_act_backward on the first cbn channels of its result):
+    the head's other channels bit for bit (same kernel body), the BatchNorm input's gradient and dgamma / dbeta to fp32 summation-order accuracy; the first cbn
+    channels of dx are left unwritten (NaN-filled here: nothing may depend on them)."""
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    g_ = torch.Generator().manual_seed(31 + n + h + cbn)
+    C_ = 128
+    w = (torch.randn(C_, 3, 3, 3, generator=g_) * 0.1).to(dev)
+    dy = torch.randn(n, 3, h, 64, generator=g_).to(dev)
+    bx = (torch.randn(n, cbn, h, 64, generator=g_) * 1.3 + 0.2).to(dev)
+    gamma = (torch.rand(cbn, generator=g_) + 0.5).to(dev); beta = (torch.randn(cbn, generator=g_) * 0.2).to(dev)
+    code, slope = {"relu": (ops.ACT_LEAKY, 0.0), "leaky": (ops.ACT_LEAKY, 0.2), "none": (ops.ACT_NONE, 0.0)}[act]
+    mean = bx.mean((0, 2, 3)); invstd = 1.0 / torch.sqrt(bx.var((0, 2, 3), unbiased=False) + 1e-5)
+    geom = ops.conv_geom(w, (1, 1), (1, 1), True)
+    L = N.lib()
+    # the two separate calls
+    dx_ref = torch.empty(n, C_, h, 64, device=dev)
+    dxd, dyd = dims5(dx_ref), dims5(dy)
+    need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(dxd), C.byref(dyd), 1)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    N.check(L.dcv_conv_backward_data(C.byref(geom), ptr(dy), C.byref(dyd), ptr(w), ptr(dx_ref), C.byref(dxd), 0, None, ptr(ws), need, stream_ptr()), "plain")
+    first = dx_ref[:, :cbn]
+    bdx_ref = torch.empty_like(bx); dgb_ref = torch.empty(2, cbn, device=dev)
+    nb = L.dcv_bn_workspace_bytes(cbn)
+    wsb = torch.empty(nb, dtype=torch.uint8, device=dev)
+    fd, bxd, bdd = dims5(first), dims5(bx), dims5(bdx_ref)
+    N.check(L.dcv_bn_act_backward(ptr(first), C.byref(fd), ptr(bx), C.byref(bxd), ptr(bdx_ref), C.byref(bdd), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), None,
+                                  1, code, slope, ptr(dgb_ref[0]), ptr(dgb_ref[1]), ptr(wsb), nb, stream_ptr()), "bn backward")
+    # the fused call
+    dx = torch.full((n, C_, h, 64), float("nan"), device=dev)
+    bdx = torch.full_like(bx, float("nan")); dgb = torch.full((2, cbn), float("nan"), device=dev)
+    need2 = L.dcv_conv_backward_data_bn_workspace_bytes(C.byref(dxd), cbn)
+    ws2 = torch.empty(need2, dtype=torch.uint8, device=dev)
+    fused = C.c_int(0)
+    N.check(L.dcv_conv_backward_data_bn(C.byref(geom), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), None, ptr(ws), need, cbn, ptr(bx), C.byref(bxd),
+                                        ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), code, slope, ptr(bdx), C.byref(bdd), ptr(dgb[0]), ptr(dgb[1]),
+                                        ptr(ws2), need2, C.byref(fused), stream_ptr()), "fused")
+    torch.cuda.synchronize()
+    assert fused.value == 1 and "head_bn_kernel<2>" in last_kernel(), last_kernel()
+    assert bool(torch.isnan(dx[:, :cbn]).all())                                    # never written
+    assert torch.equal(dx[:, cbn:], dx_ref[:, cbn:])                                # the same MFMA chain, the same stores
+    assert rel(dgb, dgb_ref) < 2e-6 and rel(bdx, bdx_ref) < 2e-6, (rel(dgb, dgb_ref), rel(bdx, bdx_ref))
