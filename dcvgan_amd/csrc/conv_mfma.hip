@@ -60,6 +60,15 @@ struct HeadBnRequest {
     int cbn; float slope;
 };
 static thread_local HeadBnRequest* t_headbn = nullptr;
+// "The first cbn channels of the operand are act(BatchNorm(bx)) and were never written": dcv_conv_forward_bn / dcv_conv_backward_weight_bn ask the RGB head's forward
+// (thin_rows_kernel) and weight gradient (thinj_wgrad_kernel) to read the BatchNorm INPUT for those channels and normalise + activate on the fly.
+struct BnView {
+    const float* bx; const float* gamma; const float* beta; const float* mean; const float* invstd;
+    int64_t bx_sn;
+    int32_t bx_sc, bx_sh, cbn, act;
+    float slope; int32_t used;
+};
+static thread_local BnView* t_bnview = nullptr;
 static inline int eff_precision() { return t_precision >= 0 ? t_precision : g_precision.load(std::memory_order_relaxed); }
 struct PrecisionScope {
     int saved;
@@ -1253,8 +1262,8 @@ __device__ __forceinline__ void xcd_plane_map(uint32_t b, uint32_t per, uint32_t
 // zero padding through bound_ctrl; 32-wide rows mask the lanes at the seam), and 4 x NH x NW x NOC FMAs run
 // on them.  Depth taps that fall outside the clip are skipped per workgroup.  The 4 waves split the channels.
 // --------------------------------------------------------------------------- //
-template <int NOC, int NH, int NW, int ND, bool W32, int IW0>
-__global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int RC) {
+template <int NOC, int NH, int NW, int ND, bool W32, int IW0, bool BN = false>
+__global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int RC, const BnView bv = BnView()) {
     constexpr int NR = NH + 3, T = ND * NH * NW, RPB = W32 ? 8 : 4;   // input rows per lane, taps per channel, output rows per block
     __shared__ float red[3][4 * NOC][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1292,15 +1301,42 @@ __global__ __launch_bounds__(256) void thin_rows_kernel(const GatherArgs a, int 
 #pragma unroll
         for (int c = 0; c < NOC; ++c) acc[p][c] = 0.f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    // BN: channels below bv.cbn are read from the BatchNorm's INPUT and normalised + activated here (their slice of the operand was never written);
+    // rows outside the image must stay the convolution's zero padding, so the transform applies to rows that exist only
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t bxrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BN ? bv.bx + (int64_t)n * bv.bx_sn : a.x), 0, 0x80000000u, 0x00020000);
+    [[maybe_unused]] uint32_t rowok = 0;
+    if constexpr (BN) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) rowok |= (vrow[q] != 0x80000000u) ? 1u << q : 0u;      // (row validity is the same for every lane of a 64-wide row)
+    }
     for (int rc = wave; rc < RC; rc += 4) {
         const f32x4* __restrict__ wrow = reinterpret_cast<const f32x4*>(a.wp) + (int64_t)rc * T;   // wave-uniform
+        [[maybe_unused]] const bool bnch = BN && rc < bv.cbn;
+        [[maybe_unused]] float bsc = 1.f, bsh = 0.f;
+        if constexpr (BN) {
+            if (bnch) {
+                const float is = bv.invstd[rc];
+                bsc = bv.gamma[rc] * is;
+                bsh = bv.beta[rc] - bv.mean[rc] * bsc;      // BnApply's expressions, operation for operation
+            }
+        }
 #pragma unroll
         for (int ud = 0; ud < ND; ++ud) {
             if (doff[ud] < 0) continue;
             const int soff = rc * a.s_stepA + doff[ud];
             float r[NR];
+            if (BN && bnch) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bxrs, vrow[q], rc * (bv.bx_sc * 4), 0));
+                    const float z = v * bsc + bsh;
+                    const float t = bv.act == DCV_ACT_LEAKY ? (z > 0.f ? z : z * bv.slope) : z;
+                    r[q] = ((rowok >> q) & 1u) ? t : 0.f;
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < NR; ++q) r[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vrow[q], soff, 0));
+            }
             f32x4 w[NH * NW];
 #pragma unroll
             for (int t = 0; t < NH * NW; ++t) w[t] = wrow[perm[ud * NH * NW + t]];
@@ -2643,8 +2679,8 @@ struct ThinJArgs {
     int32_t d_sc, d_sh, g_sc, g_sh;
 };
 
-template <int GC>
-__global__ __launch_bounds__(256, 3) void thinj_wgrad_kernel(const ThinJArgs a) {
+template <int GC, bool BN = false>
+__global__ __launch_bounds__(256, 3) void thinj_wgrad_kernel(const ThinJArgs a, const BnView bv = BnView()) {
     constexpr int PITCH = 67, RMAX = 8 + 2;
     __shared__ float gs[2][RMAX * GC][PITCH];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2681,11 +2717,34 @@ __global__ __launch_bounds__(256, 3) void thinj_wgrad_kernel(const ThinJArgs a) 
     };
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 av[2][8];
+    // BN: this wave's 32 dense channels are a BatchNorm group's output that was never written: read its INPUT, normalise + activate per element (wave-uniform choice:
+    // cbn is a multiple of 32); the channel's constants live in the lane
+    [[maybe_unused]] const bool bnw = BN && __builtin_amdgcn_readfirstlane(ch - l31) < bv.cbn;
+    [[maybe_unused]] float bsc = 1.f, bsh = 0.f;
+    [[maybe_unused]] uint32_t bvo = 0x80000000u;
+    if constexpr (BN) {
+        if (bnw) {
+            const float is = bv.invstd[ch];
+            bsc = bv.gamma[ch] * is;
+            bsh = bv.beta[ch] - bv.mean[ch] * bsc;
+            bvo = (uint32_t)(4 * (ch * bv.bx_sc + 4 * lhi));
+        }
+    }
     auto load_a = [&](int c, int rl, f32x4 (&dst)[8]) {
         const int n = c / a.cpi, y = (c - n * a.cpi) * rpc + rl;
+        if (BN && bnw) {
+            const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bv.bx + (int64_t)n * bv.bx_sn + (int64_t)y * bv.bx_sh), 0, 0x80000000u, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, bvo, 32 * q, 0));
+            return;
+        }
         const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d + (int64_t)n * a.d_sn + (int64_t)y * a.d_sh), 0, 0x80000000u, 0x00020000);
 #pragma unroll
         for (int q = 0; q < 8; ++q) dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, dvo, 32 * q, 0));
+    };
+    [[maybe_unused]] auto bn_fix = [&](float v) {
+        const float z = v * bsc + bsh;
+        return bv.act == DCV_ACT_LEAKY ? (z > 0.f ? z : z * bv.slope) : z;
     };
     f32x16 acc;
 #pragma unroll
@@ -2713,7 +2772,11 @@ __global__ __launch_bounds__(256, 3) void thinj_wgrad_kernel(const ThinJArgs a) 
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q][e], brow[8 * q + e], acc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) {
+                        float av_ = av[u][q][e];
+                        if (BN && bnw) av_ = bn_fix(av_);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, brow[8 * q + e], acc, 0, 0, 0);
+                    }
             }
         }
         if (c + 1 < c1) stage_store(buf ^ 1);
@@ -3152,6 +3215,7 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
         // the classes of an op share one launch, so the grid to fill is all of them together (depth-step classes
         // skip a varying share of their steps and measured better with the per-class count)
         int KS = gather_splits(tc.bn != 4 && !dstep ? blocks * (int)classes.size() : blocks, KIT, tc.bn == 4);
+        if (t_bnview) KS = 1;      // the normalise-on-load operand exists for the row kernel only (small batches would otherwise take the split-K gather)
         // ragged split-K (rag_plan): this class will take the LDS-DMA kernel (same conditions as the structured-walk choice below),
         // the op is not split as a whole, and a part keeps at least 8 K steps
         int rag_m0 = 0;
@@ -3426,6 +3490,13 @@ static int run_gather(const float* x, const dcv_dims5& xd, float* y, const dcv_d
                 packmax = 0;
             }
             const dim3 gr((unsigned)(M64 / 256));
+            if (BnView* bv = t_bnview) {
+                // (rows_kind 1 only: the RGB head; the operand's row pitch must be the BatchNorm input's)
+                if (rows_kind != 1 || OC != 3 || bv->bx_sh != a.x_sh || bv->cbn > RC) return fail(DCV_EUNSUPPORTED, "%s: BatchNorm-on-load is built for the 3-channel 3x3 head on 64-wide rows", tag);
+                DCV_NOTE_KERNEL("thin_rows_kernel (OC %d, kind %d, BatchNorm + activation of the first %d channels on load)", OC, rows_kind, bv->cbn);
+                hipLaunchKernelGGL((thin_rows_kernel<3, 3, 3, 1, false, -1, true>), gr, dim3(256), 0, stream, a, RC, *bv);
+                bv->used = 1;
+            } else
             if (rows_kind == 1) launch_thin_rows<3, 3, 1, false, -1>(a, OC, RC, gr, stream);
             else if (rows_kind == 2 && rows_iw0 == -1) launch_thin_rows<2, 2, 1, true, -1>(a, OC, RC, gr, stream);
             else if (rows_kind == 2) launch_thin_rows<2, 2, 1, true, 0>(a, OC, RC, gr, stream);
@@ -3776,8 +3847,17 @@ static int try_thinj_wgrad(const float* D, const dcv_dims5& dd, const float* G, 
     a.OH = OH; a.DC = DC; a.GC = GC; a.J = GC * 9; a.rpc = rpc; a.nchunk = nchunk; a.cpw = cpw; a.cpi = cpi;
     a.d_sn = dd.sn; a.g_sn = gd.sn;
     a.d_sc = (int32_t)dd.sc; a.d_sh = (int32_t)dd.sh; a.g_sc = (int32_t)gd.sc; a.g_sh = (int32_t)gd.sh;
+    if (BnView* bv = t_bnview) {
+        if (bv->bx_sc % 4 != 0 || bv->bx_sh % 4 != 0 || bv->bx_sn % 4 != 0 || (reinterpret_cast<uintptr_t>(bv->bx) & 15) != 0 || bv->cbn % 32 != 0 || bv->cbn > DC ||
+            (int64_t)bv->cbn * bv->bx_sc * 4 + (int64_t)OH * bv->bx_sh * 4 >= (1ll << 31))
+            return fail(DCV_EUNSUPPORTED, "%s: BatchNorm-on-load needs a 16-byte aligned BatchNorm input and whole 32-channel groups", tag);
+        hipLaunchKernelGGL((thinj_wgrad_kernel<3, true>), dim3((unsigned)S, (unsigned)dtiles), dim3(256), 0, stream, a, *bv);
+        bv->used = 1;
+        DCV_NOTE_KERNEL("thinj_wgrad_kernel<%d> (%d slabs, BatchNorm + activation of the first %d dense channels on load)", GC, S, bv->cbn);
+    } else {
     hipLaunchKernelGGL((thinj_wgrad_kernel<3>), dim3((unsigned)S, (unsigned)dtiles), dim3(256), 0, stream, a);
     DCV_NOTE_KERNEL("thinj_wgrad_kernel<%d> (%d slabs)", GC, S);
+    }
     DCV_LAUNCH_CHECK();
     const int J = GC * 9;
     const int64_t tot = (int64_t)DC * J;
@@ -4298,6 +4378,57 @@ int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_d
     if (!g->transposed)
         return run_wgrad(dy, *dyd, x, *xd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "conv_bwd_weight", nullptr);
     return run_wgrad(x, *xd, dy, *dyd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "convT_bwd_weight", nullptr);
+}
+
+static int bn_view_of(BnView* v, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                      int bn_act, float bn_slope, const dcv_dims5* xd, const char* tag) {
+    if (!bn_x || !bn_xd || !gamma || !beta || !mean || !invstd || !xd) return fail(DCV_EINVAL, "%s: null pointer", tag);
+    if (bn_act != DCV_ACT_NONE && bn_act != DCV_ACT_LEAKY) return fail(DCV_EUNSUPPORTED, "%s: the BatchNorm's activation must be none or (Leaky)ReLU", tag);
+    if (eff_precision() != 0) return fail(DCV_EUNSUPPORTED, "%s: fp32 path only", tag);
+    if (cbn < 1 || cbn > xd->c || bn_xd->c != cbn || bn_xd->n != xd->n || bn_xd->d != 1 || xd->d != 1 || bn_xd->h != xd->h || bn_xd->w != xd->w || bn_xd->sw != 1 ||
+        bn_xd->sn < 0 || bn_xd->sc < 0 || bn_xd->sh < 0 || (int64_t)cbn * bn_xd->sc + (int64_t)bn_xd->h * bn_xd->sh >= (1ll << 29))
+        return fail(DCV_EUNSUPPORTED, "%s: the BatchNorm input must match the operand's first channels (2-D, unit column stride)", tag);
+    memset(v, 0, sizeof(*v));
+    v->bx = bn_x; v->gamma = gamma; v->beta = beta; v->mean = mean; v->invstd = invstd;
+    v->bx_sn = bn_xd->sn; v->bx_sc = (int32_t)bn_xd->sc; v->bx_sh = (int32_t)bn_xd->sh; v->cbn = cbn; v->act = bn_act; v->slope = bn_slope;
+    return DCV_OK;
+}
+
+int dcv_conv_forward_bn(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd, int act, float slope,
+                        const dcv_wpack* pack, void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, int bn_act, float bn_slope, void* stream) {
+    // only the RGB head's geometry has the kernel: refuse everything else BEFORE anything runs (the caller then materialises the BatchNorm output: dcv_bn_apply)
+    if (!g || !xd || !yd) return fail(DCV_EINVAL, "conv_forward_bn: null pointer");
+    const bool head = g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
+                      yd->c == 3 && xd->w == 64 && yd->w == 64 && xd->h == yd->h && xd->h % 4 == 0 && xd->sw == 1 && (g->mfma == 0 || g->mfma == 1);
+    if (!head) return fail(DCV_EUNSUPPORTED, "conv_forward_bn: not the 3-channel 3x3 head on 64-wide rows");
+    BnView v;
+    int rc = bn_view_of(&v, cbn, bn_x, bn_xd, gamma, beta, save_mean, save_invstd, bn_act, bn_slope, xd, "conv_forward_bn");
+    if (rc != DCV_OK) return rc;
+    t_bnview = &v;
+    rc = conv_dispatch(0, g, x, xd, w, y, yd, act, slope, 0, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, pack);
+    t_bnview = nullptr;
+    if (rc == DCV_OK && !v.used) return fail(DCV_EINVAL, "conv_forward_bn: internal: the dispatch did not reach the head's kernel (the output was computed from an unwritten operand)");
+    return rc;
+}
+
+int dcv_conv_backward_weight_bn(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, int bn_act, float bn_slope, void* stream) {
+    if (!g || !xd || !dyd) return fail(DCV_EINVAL, "conv_backward_weight_bn: null pointer");
+    const bool head = g->transposed && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
+                      dyd->c == 3 && xd->c % 128 == 0 && xd->w == 64 && dyd->w == 64 && xd->h == dyd->h && xd->h % 2 == 0 && (g->mfma == 0 || g->mfma == 1);
+    if (!head) return fail(DCV_EUNSUPPORTED, "conv_backward_weight_bn: not the 3-channel 3x3 transposed head on 64-wide rows");
+    BnView v;
+    int rc = bn_view_of(&v, cbn, bn_x, bn_xd, gamma, beta, save_mean, save_invstd, bn_act, bn_slope, xd, "conv_backward_weight_bn");
+    if (rc != DCV_OK) return rc;
+    t_bnview = &v;
+    t_wgrad_acc = accumulate ? 1 : 0;
+    rc = dcv_conv_backward_weight(g, x, xd, dy, dyd, dw, ws, ws_bytes, stream);
+    t_wgrad_acc = 0;
+    t_bnview = nullptr;
+    if (rc == DCV_OK && !v.used) return fail(DCV_EINVAL, "conv_backward_weight_bn: internal: the dispatch did not reach the head's kernel");
+    return rc;
 }
 
 // dw = (accumulate ? dw : 0) + corr(x, dy): a weight used twice in one backward (a discriminator on the real and the fake batch, trainer.py:299-309) or whose

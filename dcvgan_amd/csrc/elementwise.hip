@@ -1258,6 +1258,30 @@ int dcv_bn_act_forward_stats(const float* x, const dcv_dims5* xd, float* y, cons
     return launch_ew(m, f, s);
 }
 
+// The two halves of dcv_bn_act_forward_stats as calls of their own, for a BatchNorm group whose OUTPUT is never written because its consumers normalise on load
+// (dcv_conv_forward_bn / dcv_conv_backward_weight_bn / dcv_conv_backward_data_bn): statistics + running-statistics update only ...
+int dcv_bn_forward_stats_only(const float* x, const dcv_dims5* xd, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                              float momentum, float eps, const float* stat, int nparts, int pitch, void* stream) {
+    if (!x || !xd || !save_mean || !save_invstd || !stat || nparts < 1 || pitch < xd->c) return fail(DCV_EINVAL, "bn_forward_stats_only: bad arguments");
+    const double count = (double)xd->n * xd->d * xd->h * xd->w;
+    hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3(xd->c), dim3(256), 0, static_cast<hipStream_t>(stream), stat, nparts, pitch, count, eps, momentum, save_mean, save_invstd,
+                       running_mean, running_var, num_batches_tracked);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+// ... and the apply pass alone (y = act(mask * (x * sc + sh)) from saved statistics): the fallback that materialises such an output after all
+int dcv_bn_apply(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                 const float* mask, int act, float slope, void* stream) {
+    if (!x || !y || !gamma || !beta || !save_mean || !save_invstd || !same_shape(*xd, *yd)) return fail(DCV_EINVAL, "bn_apply: bad arguments");
+    const dcv_dims5* views[2] = {xd, yd};
+    const void* ptrs[2] = {x, y};
+    RowMap m = make_rowmap(*xd, views, 2, ptrs);
+    if (m.groups >= (1ll << 32)) return fail(DCV_EUNSUPPORTED, "bn: tensor too large");
+    BnApply f{x, y, rv(*xd), rv(*yd), gamma, beta, save_mean, save_invstd, mask, act, slope};
+    return launch_ew(m, f, static_cast<hipStream_t>(stream));
+}
+
 int dcv_bn_act_backward(const float* dy, const dcv_dims5* dyd, const float* x, const dcv_dims5* xd, float* dx, const dcv_dims5* dxd,
                         const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, const float* mask,
                         int training, int act, float slope, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {

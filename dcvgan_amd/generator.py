@@ -192,7 +192,9 @@ class ColorVideoGenerator(nn.Module):
         h = bufs[6].join(skips[6], zc)
         # the last stage — UpBlock 5's BatchNorm -> cat with the stem's skip -> Outconv — shares an ops.BnLink: in the backward the head's data gradient and that
         # BatchNorm's backward run as one fused pair of launches (dcv_conv_backward_data_bn)
-        link = ops.BnLink()
+        # ... and in the forward that BatchNorm's output is not written at all: the head reads the BatchNorm input and normalises on load (the slice feeds nothing else;
+        # not while a test's activation-pattern tap is installed, which reads it)
+        link = ops.BnLink(defer=layers.KINK_TAP is None)
         for i, blk in enumerate(self.up_blocks):
             h = blk(h, rng, out=bufs[5 - i].first, bn_link=link if i == 5 else None)
             h = bufs[5 - i].join(h, skips[5 - i])

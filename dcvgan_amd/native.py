@@ -67,6 +67,10 @@ _SIGS = {
     "dcv_conv_forward_stats": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_data": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _P, C.c_size_t, _P]),
     "dcv_conv_backward_data_gated": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, _P]),
+    "dcv_bn_forward_stats_only": (C.c_int, [_P, _D, _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, C.c_int, C.c_int, _P]),
+    "dcv_bn_apply": (C.c_int, [_P, _D, _P, _D, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P]),
+    "dcv_conv_forward_bn": (C.c_int, [_G, _P, _D, _P, _P, _D, C.c_int, C.c_float, _P, _P, C.c_size_t, C.c_int, _P, _D, _P, _P, _P, _P, C.c_int, C.c_float, _P]),
+    "dcv_conv_backward_weight_bn": (C.c_int, [_G, _P, _D, _P, _D, _P, C.c_int, _P, C.c_size_t, C.c_int, _P, _D, _P, _P, _P, _P, C.c_int, C.c_float, _P]),
     "dcv_conv_backward_data_bn_workspace_bytes": (C.c_size_t, [_D, C.c_int]),
     "dcv_conv_backward_data_bn": (C.c_int, [_G, _P, _D, _P, _P, _D, _P, _P, C.c_size_t, C.c_int, _P, _D, _P, _P, _P, _P, C.c_int, C.c_float, _P, _D, _P, _P,
                                             _P, C.c_size_t, C.POINTER(C.c_int), _P]),

@@ -292,20 +292,30 @@ def wgrad_join_at_end(device, cur, side) -> None:
     torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
+_HEAD_BN_FUSION = os.environ.get("DCV_NO_HEAD_BN_FUSION") is None
+
+
 class BnLink:
     """Ties the BatchNorm group that writes the FIRST channels of a concat buffer to the convolution that reads the buffer (the colour generator's last stage:
     UpBlock 5 -> cat with the stem's skip -> Outconv): `bn_act(..., link=)` notes what its backward needs, `conv(..., bn_link=)`'s backward then runs
     dcv_conv_backward_data_bn — the data gradient fused with that BatchNorm's backward — and leaves the BatchNorm's results here; the BatchNorm node of the SAME
     backward pass picks them up instead of reading its cotangent (whose memory the fused kernels never wrote).  Anything the fused entry point does not take
     (another geometry, eval mode, a dropout mask, the 16-bit path) leaves the link empty and both nodes run as they always did.  DCV_NO_HEAD_BN_FUSION=1: off (A/B)."""
-    __slots__ = ("x", "gamma", "beta", "stats", "act", "slope", "task", "dx", "dgb", "stream")
+    __slots__ = ("x", "gamma", "beta", "stats", "act", "slope", "task", "dx", "dgb", "stream", "defer", "deferred", "out", "_keep")
 
-    def __init__(self):
-        self.x = self.gamma = self.beta = self.stats = self.dx = self.dgb = None
+    def __init__(self, defer: bool = False):
+        self.x = self.gamma = self.beta = self.stats = self.dx = self.dgb = self.out = None
         self.act, self.slope, self.task, self.stream = ACT_NONE, 0.0, -1, -1
+        # `defer`: the BatchNorm group may leave its OUTPUT unwritten (statistics only) — the linked convolution's forward and weight gradient then read the BatchNorm
+        # input and normalise + activate on load (dcv_conv_forward_bn / dcv_conv_backward_weight_bn); `deferred`: it did.  Only the caller knows that nothing else
+        # reads that output (the generator: the up-path slice of the last concat buffer feeds the head alone)
+        self.defer, self.deferred = bool(defer) and _HEAD_BN_FUSION and os.environ.get("DCV_NO_HEAD_BN_DEFER") is None, False
 
-
-_HEAD_BN_FUSION = os.environ.get("DCV_NO_HEAD_BN_FUSION") is None
+    def view_args(self):
+        """The (cbn, bn_x, dims, gamma, beta, mean, invstd, act, slope) tail of the *_bn entry points."""
+        bxd = dims5(self.x)
+        self._keep = bxd
+        return (self.x.shape[1], ptr(self.x), C.byref(bxd), ptr(self.gamma), ptr(self.beta), ptr(self.stats[0]), ptr(self.stats[1]), self.act, self.slope)
 
 
 class _Conv(Function):
@@ -335,6 +345,24 @@ class _Conv(Function):
         ctx.pack = pc = _pack_of(w)
         pk = pc.get(w, 0, g, x, y, xd, yd) if pc is not None else None
         pkp = C.byref(pk) if pk is not None else None
+        ctx.bn_deferred = False
+        lk = ctx.bn_link
+        if lk is not None and lk.deferred:
+            # x's first channels were never written: the head's kernel reads the BatchNorm input and normalises on load — or, for a geometry it does not take,
+            # the output is materialised now and everything proceeds as usual
+            rc = L.dcv_conv_forward_bn(C.byref(g), ptr(x), C.byref(xd), ptr(w), ptr(y), C.byref(yd), act, slope, pkp, wsp, wsn, *lk.view_args(), stream_ptr())
+            if rc == N.DCV_EUNSUPPORTED:
+                od, bxd_ = dims5(lk.out), dims5(lk.x)
+                check(L.dcv_bn_apply(ptr(lk.x), C.byref(bxd_), ptr(lk.out), C.byref(od), ptr(lk.gamma), ptr(lk.beta), ptr(lk.stats[0]), ptr(lk.stats[1]), None,
+                                     lk.act, lk.slope, stream_ptr()), "dcv_bn_apply")
+                lk.deferred = False
+            else:
+                check(rc, "dcv_conv_forward_bn")
+                _PackCache.commit(pk)
+                ctx.bn_deferred = True
+                ctx.g, ctx.act, ctx.slope = g, act, slope
+                ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+                return y
         sbytes = L.dcv_conv_stats_bytes(C.byref(g), C.byref(xd), C.byref(yd)) if (bn_stats is not None and act == ACT_NONE) else 0
         if sbytes:
             # conv -> BatchNorm pair: the epilogue leaves per-tile {sum, sum^2} of y, the BN op skips its pass over y
@@ -426,7 +454,14 @@ class _Conv(Function):
                 need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
                 wsp, wsn = _ws("conv", need, x.device)
                 tgt = grad_target(w)
-                if tgt is not None:
+                if ctx.bn_deferred:      # the operand's first channels exist only as the BatchNorm input: normalise on load
+                    if tgt is None:
+                        dw = _empty(w.shape, w.device)
+                    check(L.dcv_conv_backward_weight_bn(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt) if tgt is not None else ptr(dw),
+                                                        int(tgt is not None), wsp, wsn, *ctx.bn_link.view_args(), stream_ptr()), "dcv_conv_backward_weight_bn")
+                    if tgt is None:
+                        note_first(w, dw)
+                elif tgt is not None:
                     check(L.dcv_conv_backward_weight_acc(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
                           "dcv_conv_backward_weight_acc")
                 else:
@@ -441,7 +476,14 @@ class _Conv(Function):
             need = L.dcv_conv_workspace_bytes(C.byref(g), C.byref(xd), C.byref(dyd), 2)
             wsp, wsn = _ws("conv", need, x.device)
             tgt = grad_target(w) if _OWN_ACCUMULATION else None
-            if tgt is not None:
+            if ctx.bn_deferred:
+                if tgt is None:
+                    dw = _empty(w.shape, w.device)
+                check(L.dcv_conv_backward_weight_bn(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt) if tgt is not None else ptr(dw),
+                                                    int(tgt is not None), wsp, wsn, *ctx.bn_link.view_args(), stream_ptr()), "dcv_conv_backward_weight_bn")
+                if tgt is None and _OWN_ACCUMULATION:
+                    note_first(w, dw)
+            elif tgt is not None:
                 # a later contribution (second use in this backward, or .grad from an earlier backward): the slab reduce adds into the tensor that holds the first
                 check(L.dcv_conv_backward_weight_acc(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), C.c_void_p(tgt), 1, wsp, wsn, stream_ptr()),
                       "dcv_conv_backward_weight_acc")
@@ -490,7 +532,16 @@ class _BnAct(Function):
         stats = _empty((2, Cn), x.device)
         xd, yd = dims5(x), dims5(y)
         wsp, wsn = _ws("bn", L.dcv_bn_workspace_bytes(Cn), x.device)
-        if partials is not None and training:
+        if link is not None:
+            link.deferred = False
+        if link is not None and link.defer and partials is not None and training and mask is None and act in (ACT_NONE, ACT_LEAKY) and x.dim() == 4 and x.is_contiguous() \
+                and x.shape[3] == 64 and x.shape[1] % 32 == 0:
+            # statistics only: the output slice stays unwritten, the linked head normalises on load (BnLink.defer)
+            stat, nparts, pitch = partials.v
+            check(L.dcv_bn_forward_stats_only(ptr(x), C.byref(xd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(stats[0]), ptr(stats[1]), momentum, eps,
+                                              ptr(stat), nparts, pitch, stream_ptr()), "dcv_bn_forward_stats_only")
+            link.deferred, link.out = True, y
+        elif partials is not None and training:
             stat, nparts, pitch = partials.v
             check(L.dcv_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),
                                              ptr(stats[0]), ptr(stats[1]), ptr(mask), momentum, eps, act, slope, ptr(stat), nparts, pitch,

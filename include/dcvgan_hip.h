@@ -63,7 +63,7 @@ typedef struct dcv_conv_geom {
 } dcv_conv_geom;
 
 const char* dcv_last_error(void);
-/* ABI version.  4 (round 6): dcv_scale_dev, dcv_conv_backward_data_bn(_workspace_bytes) exist (no struct changed).  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
+/* ABI version.  4 (round 6): dcv_scale_dev, dcv_conv_backward_data_bn(_workspace_bytes), dcv_conv_forward_bn, dcv_conv_backward_weight_bn, dcv_bn_forward_stats_only, dcv_bn_apply exist (no struct changed).  3 (round 5): dcv_conv_backward_weight_acc / dcv_cl_conv_backward_weight_acc, dcv_cl_conv_backward_data_gated, dcv_clf16_*, dcv_normal_fill_many exist (no struct changed).
  * 2 (round 4): dcv_conv_geom has the 13th field `mfma`, dcv_wpack the 4th field `precision`, dcv_abi_struct_sizes exists.
  * A host compares dcv_version() and dcv_abi_struct_sizes() with its own declarations BEFORE the first call that passes a struct
  * (dcvgan_amd/native.py does, and refuses to load on a mismatch): the library cannot see the size of what a pointer points to. */
@@ -140,6 +140,22 @@ int dcv_conv_backward_data_gated(const dcv_conv_geom* g, const float* dy, const 
                                  float* dx, const dcv_dims5* dxd, int accumulate,
                                  const float* x, const dcv_dims5* xd, int act, float slope, const dcv_wpack* pack,
                                  void* ws, size_t ws_bytes, void* stream);
+/* A BatchNorm (+ activation) group whose output is NEVER WRITTEN (round 6; the colour generator's UpBlock 5, generator.py:238-250: 1.17 GB per pass at B = 70 that
+ * only the RGB head reads): dcv_bn_forward_stats_only finalises the statistics the producing convolution's epilogue left (dcv_conv_forward_stats) and updates the running
+ * statistics; the head's forward (dcv_conv_forward_bn) and weight gradient (dcv_conv_backward_weight_bn) then read the BatchNorm INPUT for the operand's first cbn
+ * channels and apply act(x * gamma * invstd + beta - mean * gamma * invstd) on load, and dcv_conv_backward_data_bn (below) is the matching backward.
+ * The *_bn conv entries take only the head's geometry (3x3 / 1 / 1, 3 output channels, 64-wide rows, fp32) and return DCV_EUNSUPPORTED for anything else BEFORE running
+ * anything; a caller that gets that materialises the output with dcv_bn_apply and uses the plain entries. */
+int dcv_bn_forward_stats_only(const float* x, const dcv_dims5* xd, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd,
+                              float momentum, float eps, const float* stat, int nparts, int pitch, void* stream);
+int dcv_bn_apply(const float* x, const dcv_dims5* xd, float* y, const dcv_dims5* yd, const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                 const float* mask, int act, float slope, void* stream);
+int dcv_conv_forward_bn(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* w, float* y, const dcv_dims5* yd, int act, float slope,
+                        const dcv_wpack* pack, void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, int bn_act, float bn_slope, void* stream);
+int dcv_conv_backward_weight_bn(const dcv_conv_geom* g, const float* x, const dcv_dims5* xd, const float* dy, const dcv_dims5* dyd, float* dw, int accumulate,
+                                void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_invstd, int bn_act, float bn_slope, void* stream);
 /* The data gradient of a convolution whose first `cbn` input channels are the output of a BatchNorm (training mode, no dropout mask) + (Leaky)ReLU | identity, FUSED
  * with that BatchNorm's backward — the last stage of the colour generator: `UpBlock` 5 -> torch.cat with the stem's skip -> `Outconv`
  * (generator.py:238-250,272-277,393-400).  Where the geometry is the RGB head's (3x3 / stride 1 / pad 1 transposed, 3 -> 128 channels on 64-wide rows, fp32) the gradient

@@ -166,3 +166,51 @@ def test_head_data_gradient_fused_with_the_batchnorm_backward(dev, n, h, cbn, ac
     assert bool(torch.isnan(dx[:, :cbn]).all())                                    # never written
     assert torch.equal(dx[:, cbn:], dx_ref[:, cbn:])                                # the same MFMA chain, the same stores
     assert rel(dgb, dgb_ref) < 2e-6 and rel(bdx, bdx_ref) < 2e-6, (rel(dgb, dgb_ref), rel(bdx, bdx_ref))
+
+
+@pytest.mark.parametrize("n,h,cbn,act", [(5, 64, 64, "relu"), (3, 32, 64, "leaky"), (2, 16, 32, "none")], ids=lambda v: str(v))
+def test_head_forward_and_weight_gradient_normalise_on_load(dev, n, h, cbn, act):
+    """dcv_conv_forward_bn / dcv_conv_backward_weight_bn: the operand's first cbn channels are NaN (never written); the kernels read the BatchNorm input instead and
+    apply act(x * sc + sh) on load — against the plain entries on the materialised operand (dcv_bn_apply), to fp32 summation-order accuracy; padding rows stay zero
+    (first / last output rows and columns compared separately)."""
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    g_ = torch.Generator().manual_seed(77 + n + h + cbn)
+    C_ = 128
+    w = (torch.randn(C_, 3, 3, 3, generator=g_) * 0.1).to(dev)
+    bx = (torch.randn(n, cbn, h, 64, generator=g_) * 1.3 + 0.2).to(dev)
+    gamma = (torch.rand(cbn, generator=g_) + 0.5).to(dev); beta = (torch.randn(cbn, generator=g_) * 0.2).to(dev)
+    code, slope = {"relu": (ops.ACT_LEAKY, 0.0), "leaky": (ops.ACT_LEAKY, 0.2), "none": (ops.ACT_NONE, 0.0)}[act]
+    mean = bx.mean((0, 2, 3)); invstd = 1.0 / torch.sqrt(bx.var((0, 2, 3), unbiased=False) + 1e-5)
+    rest = torch.randn(n, C_ - cbn, h, 64, generator=g_).to(dev)
+    dy = torch.randn(n, 3, h, 64, generator=g_).to(dev)
+    geom = ops.conv_geom(w, (1, 1), (1, 1), True)
+    L = N.lib()
+    full = torch.empty(n, C_, h, 64, device=dev); full[:, cbn:] = rest
+    first = full[:, :cbn]
+    bxd, fd = dims5(bx), dims5(first)
+    N.check(L.dcv_bn_apply(ptr(bx), C.byref(bxd), ptr(first), C.byref(fd), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), None, code, slope, stream_ptr()), "bn_apply")
+    z = (bx * (gamma * invstd)[None, :, None, None] + (beta - mean * gamma * invstd)[None, :, None, None])
+    want_first = torch.where(z > 0, z, z * slope) if code == ops.ACT_LEAKY else z
+    assert rel(first, want_first) < 1e-6
+    holey = torch.full((n, C_, h, 64), float("nan"), device=dev); holey[:, cbn:] = rest
+    y_ref = torch.empty(n, 3, h, 64, device=dev); y = torch.empty_like(y_ref)
+    xd, yd = dims5(full), dims5(y)
+    need = max(L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(xd), C.byref(yd), 0), L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(xd), C.byref(yd), 2))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    N.check(L.dcv_conv_forward(C.byref(geom), ptr(full), C.byref(xd), ptr(w), ptr(y_ref), C.byref(yd), ops.ACT_TANH, 0.0, None, ptr(ws), need, stream_ptr()), "fwd")
+    tail = (cbn, ptr(bx), C.byref(bxd), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), code, slope)
+    N.check(L.dcv_conv_forward_bn(C.byref(geom), ptr(holey), C.byref(xd), ptr(w), ptr(y), C.byref(yd), ops.ACT_TANH, 0.0, None, ptr(ws), need, *tail, stream_ptr()), "fwd bn")
+    assert "on load" in last_kernel(), last_kernel()
+    assert bool(torch.isfinite(y).all()) and rel(y, y_ref) < 1e-6      # (small batches take the split-K gather on the plain entry: another summation order)
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), h - 1), (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), 63)):
+        assert rel(y[sl], y_ref[sl]) < 1e-6                              # the padding rows / columns stayed zero under the transform
+    dw_ref = torch.empty_like(w); dw = torch.empty_like(w)
+    N.check(L.dcv_conv_backward_weight(C.byref(geom), ptr(full), C.byref(xd), ptr(dy), C.byref(yd), ptr(dw_ref), ptr(ws), need, stream_ptr()), "wgrad")
+    N.check(L.dcv_conv_backward_weight_bn(C.byref(geom), ptr(holey), C.byref(xd), ptr(dy), C.byref(yd), ptr(dw), 0, ptr(ws), need, *tail, stream_ptr()), "wgrad bn")
+    assert "on load" in last_kernel(), last_kernel()
+    assert bool(torch.isfinite(dw).all()) and rel(dw, dw_ref) < 1e-6
+    # a geometry the head's kernels do not take is refused before anything runs
+    w4 = torch.randn(C_, 4, 3, 3, device=dev); g4 = ops.conv_geom(w4, (1, 1), (1, 1), True)
+    y4 = torch.empty(n, 4, h, 64, device=dev); y4d = dims5(y4)
+    assert L.dcv_conv_forward_bn(C.byref(g4), ptr(holey), C.byref(xd), ptr(w4), ptr(y4), C.byref(y4d), 0, 0.0, None, ptr(ws), need, *tail, stream_ptr()) == N.DCV_EUNSUPPORTED
