@@ -4380,6 +4380,15 @@ int dcv_conv_backward_weight(const dcv_conv_geom* g, const float* x, const dcv_d
     return run_wgrad(x, *xd, dy, *dyd, dw, k, s, p, ws, ws_bytes, static_cast<hipStream_t>(stream), "convT_bwd_weight", nullptr);
 }
 
+// The geometry BOTH normalise-on-load kernels take (the forward must only leave the BatchNorm output unwritten where the weight gradient can do without it too):
+// the 3x3 / 1 / 1 transposed head with 3 output channels on 64-wide rows, 128 k input channels, whole 32-channel BatchNorm groups, 16-byte aligned BatchNorm input
+static bool head_on_load_ok(const dcv_conv_geom* g, const dcv_dims5* xd, const dcv_dims5* yd, int cbn, const float* bn_x, const dcv_dims5* bn_xd) {
+    return g->transposed && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
+           yd->c == 3 && xd->c % 128 == 0 && xd->w == 64 && yd->w == 64 && xd->h == yd->h && xd->h % 4 == 0 && xd->sw == 1 && (g->mfma == 0 || g->mfma == 1) &&
+           cbn % 32 == 0 && cbn > 0 && cbn <= xd->c && bn_xd && bn_xd->sc % 4 == 0 && bn_xd->sh % 4 == 0 && bn_xd->sn % 4 == 0 && bn_xd->sh == xd->sh &&
+           (reinterpret_cast<uintptr_t>(bn_x) & 15) == 0 && xd->sc % 4 == 0 && xd->sh % 4 == 0 && xd->sn % 4 == 0;
+}
+
 static int bn_view_of(BnView* v, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta, const float* mean, const float* invstd,
                       int bn_act, float bn_slope, const dcv_dims5* xd, const char* tag) {
     if (!bn_x || !bn_xd || !gamma || !beta || !mean || !invstd || !xd) return fail(DCV_EINVAL, "%s: null pointer", tag);
@@ -4399,9 +4408,8 @@ int dcv_conv_forward_bn(const dcv_conv_geom* g, const float* x, const dcv_dims5*
                         const float* save_mean, const float* save_invstd, int bn_act, float bn_slope, void* stream) {
     // only the RGB head's geometry has the kernel: refuse everything else BEFORE anything runs (the caller then materialises the BatchNorm output: dcv_bn_apply)
     if (!g || !xd || !yd) return fail(DCV_EINVAL, "conv_forward_bn: null pointer");
-    const bool head = g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
-                      yd->c == 3 && xd->w == 64 && yd->w == 64 && xd->h == yd->h && xd->h % 4 == 0 && xd->sw == 1 && (g->mfma == 0 || g->mfma == 1);
-    if (!head) return fail(DCV_EUNSUPPORTED, "conv_forward_bn: not the 3-channel 3x3 head on 64-wide rows");
+    if (!head_on_load_ok(g, xd, yd, cbn, bn_x, bn_xd) || (x && (reinterpret_cast<uintptr_t>(x) & 15) != 0))
+        return fail(DCV_EUNSUPPORTED, "conv_forward_bn: not the 3-channel 3x3 transposed head on 64-wide rows with 128 k input channels");
     BnView v;
     int rc = bn_view_of(&v, cbn, bn_x, bn_xd, gamma, beta, save_mean, save_invstd, bn_act, bn_slope, xd, "conv_forward_bn");
     if (rc != DCV_OK) return rc;
@@ -4416,9 +4424,8 @@ int dcv_conv_backward_weight_bn(const dcv_conv_geom* g, const float* x, const dc
                                 void* ws, size_t ws_bytes, int cbn, const float* bn_x, const dcv_dims5* bn_xd, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_invstd, int bn_act, float bn_slope, void* stream) {
     if (!g || !xd || !dyd) return fail(DCV_EINVAL, "conv_backward_weight_bn: null pointer");
-    const bool head = g->transposed && g->kd == 1 && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->sh == 1 && g->sw == 1 && g->pd == 0 && g->ph == 1 && g->pw == 1 &&
-                      dyd->c == 3 && xd->c % 128 == 0 && xd->w == 64 && dyd->w == 64 && xd->h == dyd->h && xd->h % 2 == 0 && (g->mfma == 0 || g->mfma == 1);
-    if (!head) return fail(DCV_EUNSUPPORTED, "conv_backward_weight_bn: not the 3-channel 3x3 transposed head on 64-wide rows");
+    if (!head_on_load_ok(g, xd, dyd, cbn, bn_x, bn_xd))
+        return fail(DCV_EUNSUPPORTED, "conv_backward_weight_bn: not the 3-channel 3x3 transposed head on 64-wide rows with 128 k input channels");
     BnView v;
     int rc = bn_view_of(&v, cbn, bn_x, bn_xd, gamma, beta, save_mean, save_invstd, bn_act, bn_slope, xd, "conv_backward_weight_bn");
     if (rc != DCV_OK) return rc;
