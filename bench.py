@@ -635,6 +635,10 @@ def main():
         dog.start()
         res = None
         try:
+            for b_ in {id(o.bucket): o.bucket for o in opts.values()}.values():      # the headline's buckets let go of the parameters (their hooks would fire beside the new ones)
+                for h_ in b_._hooks:
+                    h_.remove()
+                b_._hooks = []
             o3 = trainer.build_optimizers(cfg, models, data_parallel=True, overlap=True)
             r3 = trainer.StepRunner(cfg, models, o3, trainer.build_loss(cfg), sync_losses=False)
             r3.iteration = runner.iteration
