@@ -82,3 +82,23 @@ def test_bench_spawns_its_own_ranks(precision):
     for ph in ("D", "G"):
         assert dp[f"collective_{ph}_phase"]["ms_per_step"] > 0 and dp[f"collective_{ph}_phase"]["bytes_per_step"] > 0, dp
     assert dp["dp_overlap"].get("ms_per_step", 0) > 0 and dp["dp_overlap"]["early_collectives_G_bucket"] > 0, dp["dp_overlap"]
+
+
+def test_bench_under_the_drivers_launcher():
+    """The command line the driver uses for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`): RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher, bench.py must not spawn ranks of its own, and exactly one JSON line comes out
+    (rank 0's).  Two ranks on this one card, hence gloo and --all-ranks-on-device0; the launcher itself never touches the GPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "LOCAL_WORLD_SIZE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--all-ranks-on-device0", "--backend", "gloo", "--batch", "4", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-minimal", "--no-as-trainer", "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2"
+    assert r["value"] > 0 and r["data_parallel"]["world"] == 2 and r["data_parallel"]["backend"] == "gloo"
+    assert r["data_parallel"]["dp_overlap"].get("ms_per_step", 0) > 0, r["data_parallel"]["dp_overlap"]      # the leg the driver's own N > 1 run will execute too
