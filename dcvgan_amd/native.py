@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCV_LIB_PATH") or os.path.join(_HERE, "libdcvgan_hip.so")      # DCV_LIB_PATH: another build of the same library (A/B runs of tools/)
 
 ACT_NONE, ACT_LEAKY, ACT_TANH = 0, 1, 2
-DCV_EUNSUPPORTED = -4
+DCV_OK, DCV_EINVAL, DCV_EWORKSPACE, DCV_EHIP, DCV_EUNSUPPORTED = 0, -1, -2, -3, -4      # include/dcvgan_hip.h
 
 
 class NativeError(RuntimeError):

@@ -214,3 +214,43 @@ def test_head_forward_and_weight_gradient_normalise_on_load(dev, n, h, cbn, act)
     w4 = torch.randn(C_, 4, 3, 3, device=dev); g4 = ops.conv_geom(w4, (1, 1), (1, 1), True)
     y4 = torch.empty(n, 4, h, 64, device=dev); y4d = dims5(y4)
     assert L.dcv_conv_forward_bn(C.byref(g4), ptr(holey), C.byref(xd), ptr(w4), ptr(y4), C.byref(y4d), 0, 0.0, None, ptr(ws), need, *tail, stream_ptr()) == N.DCV_EUNSUPPORTED
+
+
+def test_round6_entries_refuse_bad_arguments(dev):
+    """Error behaviour of the round-6 entry points, checked before anything is launched (the launch counter does not move): null operands -> DCV_EINVAL, a BatchNorm
+    activation the fused backward cannot differentiate -> DCV_EUNSUPPORTED, a second workspace below dcv_conv_backward_data_bn_workspace_bytes -> DCV_EWORKSPACE."""
+    from dcvgan_amd import native as N, ops
+    from dcvgan_amd.native import dims5, ptr, stream_ptr
+    L = N.lib()
+    n, h, cbn, C_ = 2, 8, 64, 128
+    w = torch.randn(C_, 3, 3, 3, device=dev) * 0.1
+    geom = ops.conv_geom(w, (1, 1), (1, 1), True)
+    dy = torch.randn(n, 3, h, 64, device=dev); dx = torch.empty(n, C_, h, 64, device=dev)
+    bx = torch.randn(n, cbn, h, 64, device=dev); bdx = torch.empty_like(bx)
+    v = torch.ones(cbn, device=dev); dg = torch.empty(cbn, device=dev); db = torch.empty(cbn, device=dev)
+    dyd, dxd, bxd = dims5(dy), dims5(dx), dims5(bx)
+    need = L.dcv_conv_workspace_bytes(C.byref(geom), C.byref(dxd), C.byref(dyd), 1)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    L.dcv_conv_backward_data_bn_workspace_bytes.restype = C.c_size_t
+    need2 = L.dcv_conv_backward_data_bn_workspace_bytes(C.byref(dxd), cbn)
+    assert need2 > 0
+    ws2 = torch.empty(need2, dtype=torch.uint8, device=dev)
+    fused = C.c_int(-1)
+
+    def bwd(dy_p, act, ws2_bytes):
+        return L.dcv_conv_backward_data_bn(C.byref(geom), dy_p, C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), None, ptr(ws), ws.numel(), cbn, ptr(bx), C.byref(bxd),
+                                           ptr(v), ptr(v), ptr(v), ptr(v), act, 0.0, ptr(bdx), C.byref(bxd), ptr(dg), ptr(db), ptr(ws2), ws2_bytes, C.byref(fused), stream_ptr())
+    before = L.dcv_launch_count()
+    assert bwd(None, ops.ACT_LEAKY, need2) == N.DCV_EINVAL
+    assert bwd(ptr(dy), ops.ACT_TANH, need2) == N.DCV_EUNSUPPORTED
+    assert bwd(ptr(dy), ops.ACT_LEAKY, need2 - 1) == N.DCV_EWORKSPACE
+    s1 = torch.ones((), device=dev)
+    assert L.dcv_scale_dev(None, 4, ptr(s1), ptr(dg), stream_ptr()) == N.DCV_EINVAL
+    assert L.dcv_scale_dev(ptr(dg), -1, ptr(s1), ptr(dg), stream_ptr()) == N.DCV_EINVAL
+    assert L.dcv_bn_apply(None, C.byref(bxd), ptr(bdx), C.byref(bxd), ptr(v), ptr(v), ptr(v), ptr(v), None, ops.ACT_NONE, 0.0, stream_ptr()) == N.DCV_EINVAL
+    assert L.dcv_bn_forward_stats_only(ptr(bx), C.byref(bxd), None, None, None, ptr(v), ptr(v), 0.1, 1e-5, None, 1, cbn, stream_ptr()) == N.DCV_EINVAL
+    assert L.dcv_launch_count() == before
+    assert b"" != L.dcv_last_error()
+    # ... and the same call with good arguments runs and reports the fused path
+    N.check(bwd(ptr(dy), ops.ACT_LEAKY, need2), "dcv_conv_backward_data_bn")
+    assert fused.value == 1 and bool(torch.isfinite(bdx).all()) and bool(torch.isfinite(dx[:, cbn:]).all())
