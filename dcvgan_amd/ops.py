@@ -540,7 +540,8 @@ class _BnAct(Function):
             stat, nparts, pitch = partials.v
             check(L.dcv_bn_forward_stats_only(ptr(x), C.byref(xd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(stats[0]), ptr(stats[1]), momentum, eps,
                                               ptr(stat), nparts, pitch, stream_ptr()), "dcv_bn_forward_stats_only")
-            link.deferred, link.out = True, y
+            link.deferred, link.out = True, y.detach()      # an alias WITHOUT this node as its grad_fn: link -> y -> grad_fn (this ctx) -> link would be a reference cycle that
+                                                            # keeps x and y (1.17 GB each at B = 70) allocated until Python's cyclic collector happens to run (tools/cycle_probe.py)
         elif partials is not None and training:
             stat, nparts, pitch = partials.v
             check(L.dcv_bn_act_forward_stats(ptr(x), C.byref(xd), ptr(y), C.byref(yd), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(nbt),

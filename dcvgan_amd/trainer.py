@@ -13,6 +13,7 @@ reference's four ``.cpu().item()`` host syncs per iteration.
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import Dict, Optional
 
@@ -85,6 +86,12 @@ class StepRunner:
         # diagnostics (tools/phases.py): HIP events on the main stream at the phase boundaries of an iteration; None = off (no event is ever recorded)
         self.phase_marks = None
         self._ones = {}
+        # How many iterations the host may enqueue ahead of the GPU.  The reference's loop reads the losses on the host every iteration (trainer.py:326-328,363) and is
+        # never ahead; a caller that does not (bench.py, sync_losses=False) enqueues an iteration in about a third of the time the GPU takes to run it, and every tensor
+        # that crossed streams is only returned to the allocator when the GPU reaches its last use — without a bound the memory in flight grows with the lead (soak at
+        # B = 70: 37 GB after 5 iterations, 146 GB allocated / 191 GB reserved after 150).  Two iterations keep the GPU's queues full and the memory flat.
+        self.max_ahead = max(1, int(os.environ.get("DCV_MAX_ITERATIONS_AHEAD", "2")))
+        self._inflight = collections.deque()
 
     def _mark(self, name):
         if self.phase_marks is not None:
@@ -145,6 +152,9 @@ class StepRunner:
         c, m, o = self.cfg, self.models, self.opt
         ggen, cgen, idis, vdis, gdis = (m[k] for k in MODEL_NAMES)
         self.iteration += 1
+        if xc_real.is_cuda:
+            while len(self._inflight) >= self.max_ahead:
+                self._inflight.popleft().synchronize()      # the host waits for iteration i - max_ahead to END: no kernel of the current queue is delayed
         # ---- discriminator phase (trainer.py:285-328) ----
         for d in (idis, vdis, gdis):
             d.train()
@@ -193,4 +203,8 @@ class StepRunner:
         else:
             loss_gen.detach_()
         out["loss_gen"] = loss_gen.cpu().item() if self.sync_losses else loss_gen.detach()     # trainer.py:363
+        if xc_real.is_cuda:
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream())      # (the lanes and the companion stream have joined the main stream by now)
+            self._inflight.append(e)
         return out

@@ -31,6 +31,7 @@ for i in range(N):
     out = runner.step(xc, xg, i % 16)
     if i in (5, 20, N // 2, N - 1) or (os.environ.get('SOAK_VERBOSE') and i % 20 in (0, 1)):
         torch.cuda.synchronize()
+        torch.empty(1, device=dev)      # an allocation lets the allocator take back blocks that were freed on other streams
         marks.append((i, torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e3,
                       {k: round(float(v), 4) for k, v in out.items()}))
 for m in marks:
