@@ -2846,6 +2846,135 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // --------------------------------------------------------------------------- //
+// stem3d_wgrad_kernel<CIN>: weight gradient of the 3-D discriminators' stems — Conv3d(CIN -> 32, 4x4x4, stride (1,2,2), padding (0,1,1)) on 64-wide frames
+// (discriminator.py: the depth / flow and colour branches of VideoDiscriminator, GradientDiscriminator's first layer; CIN = 1, 2, 3), R[oc][j] = sum_m dy[oc][m]
+// xg[j][m] with J = 64 CIN rows j = (c, kd, kh, kw).  The generic tile kernel runs it as a 32 x 128 / 32 x 256 tile over ~970 position slabs: half of the tile is
+// padding for one input channel, every input element is gathered 16 times through the texture path, 0.16-0.32 of the MFMA rate — and the iteration pays those nine
+// launches' 1.5 ms nearly one for one (profiles/r06_ab_small_experiments.txt).  Here ONE WAVE owns a run of output rows (n, od, oh) and all J columns:
+//   * per output row it stages, by wave-private 16-byte LDS-DMA one row ahead, the dy row of the 32 channels (4 instructions: 8 channels x 8 granules each) and the 4
+//     input rows 2 oh - 1 .. 2 oh + 2 of each of the 4 CIN (channel, depth tap) planes (ONE instruction per plane: 4 rows x 16 granules; rows outside the frame
+//     arrive as zeros).  An LDS-DMA lands lane-linear, so both images are permuted on the SOURCE side: dy granule g of channel oc sits at g ^ ((oc >> 1) & 7) — the
+//     A fragment "32 channels x four positions" is then a conflict-free ds_read_b128 that serves two K steps; x granule c of row kh of plane pl sits at
+//     c ^ (kh + 4 (pl & 1)) — the B fragment, a lane per tap (kd & 1, kh, kw) at one position, reads 32 different banks (the first version's dword DMAs, 16 + 16 CIN per
+//     row at ~90 cycles of issue each, cost as much as the row's MFMAs);
+//   * a K step is two neighbouring positions; the taps that fall on the column halo (kw = 0 at the first position, kw = 3 at the last) are zeroed in the two steps
+//     where they occur; the step's B addresses are one XOR away from lane constants, the column tile is an immediate; 2 CIN MFMAs per step share the dy fragment;
+//   * no workgroup barrier anywhere (a workgroup IS a wave: its own vmcnt orders the DMAs before its reads), 16-32 KB of LDS: 4-8 waves per CU;
+//   * partial sums leave as one slab per wave, [32][J] = dw's own layout; wgrad_reduce4_kernel adds the slabs in a fixed order (also into an existing gradient).
+// Rows per wave and the wave count depend on the shape only: bitwise reproducible.  Roofline: MFMA for 3 channels (0.07 ms at B = 70), HBM for 1 (0.03 ms).
+// --------------------------------------------------------------------------- //
+struct Stem3Args {
+    const float* d; const float* g; float* slab;
+    int64_t d_sn, g_sn;
+    int32_t d_sc, d_sd, d_sh;      // dy element strides (unit column stride)
+    int32_t g_sc, g_sd, g_sh;      // x element strides (unit column stride)
+    int32_t OD, OH, H;             // output depth planes, output rows, input rows
+    int32_t rows, rpw;             // N * OD * OH output rows; rows per workgroup (= wave)
+    int32_t J;
+};
+
+// NS stages: the DMAs of output row r + NS - 1 are issued at the top of row r (the loop is bound by the DMA round trip, not by the MFMAs, when a row's MFMAs are few)
+template <int CIN, int NS>
+__global__ __launch_bounds__(64) void stem3d_wgrad_kernel(const Stem3Args a) {
+    constexpr int NT = 2 * CIN;                      // 32-column tiles
+    constexpr int XW = CIN * 4 * 256, BUF = XW + 1024;      // words of a stage: [plane][4 rows][64 columns], then the dy row [32 oc][32 positions]
+    constexpr int PER_ROW = 4 * CIN + 4;             // DMA instructions of a row
+    static_assert(NS >= 2 && NS <= 4, "2-4 stages");
+    __shared__ __attribute__((aligned(16))) float smem[NS * BUF];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+    const int r0 = (int)blockIdx.x * a.rpw, r1 = min(a.rows, r0 + a.rpw);
+    // DMA offsets (bytes inside the sample).  dy, instruction t: lane = (channel 8 t + (lane >> 3), slot granule lane & 7) fetches granule slot ^ ((oc >> 1) & 7)
+    uint32_t dvo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int oc = 8 * t + (lane >> 3);
+        dvo[t] = (uint32_t)(4 * (oc * a.d_sc + 4 * ((lane & 7) ^ ((oc >> 1) & 7))));
+    }
+    // x, one instruction per plane: lane = (row lane >> 4, slot granule lane & 15) fetches granule slot ^ (row + 4 (plane & 1)); the row offset joins per output row
+    const int xrow = lane >> 4;
+    const uint32_t xg0 = (uint32_t)(16 * ((lane & 15) ^ xrow)), xg1 = (uint32_t)(16 * ((lane & 15) ^ (xrow + 4)));
+    // fragment addresses (bytes inside a stage)
+    const uint32_t A0 = (uint32_t)(4 * (XW + l31 * 32)), f4 = (uint32_t)(((l31 >> 1) & 7) * 16);
+    // B: lane = tap (kdl = l31 >> 4, kh, kw) at position 2 st + lhi: column C = 4 st + T, T = 2 lhi + kw - 1 in [-1, 4] -> granule st + e, word cw
+    const int kdl = l31 >> 4, kh = (l31 >> 2) & 3, T = 2 * lhi + (l31 & 3) - 1;
+    const int e = T < 0 ? -1 : T > 3 ? 1 : 0, cw = T & 3;
+    const uint32_t sw = (uint32_t)(kh + 4 * kdl);
+    const uint32_t B0 = (uint32_t)(4 * (kdl * 256 + kh * 64 + cw));
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int per_n = a.OD * a.OH;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto issue = [&](int rr, int buf) {
+        const int n = rr / per_n, rem = rr - n * per_n;
+        const int od = rem / a.OH, oh = rem - od * a.OH;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g + (int64_t)n * a.g_sn), 0, 0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.d + (int64_t)n * a.d_sn), 0, 0x80000000u, 0x00020000);
+        float* xb = smem + buf * BUF;
+        const int ih = 2 * oh - 1 + xrow;                            // this lane's input row
+        const uint32_t rowo = (unsigned)ih < (unsigned)a.H ? (uint32_t)(4 * ih * a.g_sh) : 0x80000000u;      // outside the frame: zeros
+#pragma unroll
+        for (int pl = 0; pl < CIN * 4; ++pl)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(xb + pl * 256), 16, rowo + ((pl & 1) ? xg1 : xg0), 4 * ((pl >> 2) * a.g_sc + (od + (pl & 3)) * a.g_sd), 0, 0);
+        const int dso = 4 * (od * a.d_sd + oh * a.d_sh);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(xb + XW + t * 256), 16, dvo[t], dso, 0, 0);
+    };
+#else
+    auto issue = [&](int, int) { (void)dvo; (void)xg0; (void)xg1; (void)per_n; (void)xrow; };
+#endif
+
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (r0 + i < r1) issue(r0 + i, i);
+    int buf = 0;
+    for (int rr = r0; rr < r1; ++rr) {
+        // this row's DMAs have landed: only the younger rows' (issued after it) may still be in flight
+        const int younger = min(NS - 2, r1 - 1 - rr);
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_ROW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_ROW) : "memory");
+        if (rr + NS - 1 < r1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads of the stage about to be refilled (the row before) have returned
+            issue(rr + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        }
+        const char* sb = reinterpret_cast<const char*>(smem) + buf * (BUF * 4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(sb + A0 + ((uint32_t)(16 * q) ^ f4));      // positions 4 q .. 4 q + 3 of this lane's channel
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int st = 2 * q + u;
+                const float av = lhi ? a4[2 * u + 1] : a4[2 * u];
+                const bool halo = (st == 0 && e < 0) || (st == 15 && e > 0);      // (false at compile time for the other steps)
+                const int ge = st == 0 ? max(st + e, 0) : st == 15 ? min(st + e, 15) : st + e;
+                const uint32_t bo = B0 + 16u * ((uint32_t)ge ^ sw);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float bv = *reinterpret_cast<const float*>(sb + bo + 4 * ((t >> 1) * 1024 + (t & 1) * 512));
+                    if (st == 0 || st == 15) bv = halo ? 0.f : bv;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* __restrict__ out = a.slab + (int64_t)blockIdx.x * 32 * a.J;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            out[oc * a.J + 32 * t + l31] = acc[t][r];
+        }
+}
+
+// --------------------------------------------------------------------------- //
 // host side: plans (index tables cached on the device per distinct geometry)
 // --------------------------------------------------------------------------- //
 struct DevTable {
@@ -3866,6 +3995,59 @@ static int try_thinj_wgrad(const float* D, const dcv_dims5& dd, const float* G, 
     return DCV_OK;
 }
 
+// the 3-D discriminators' stems (stem3d_wgrad_kernel): -1 = not this shape
+static int try_stem3d_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R, const int k[3], const int s[3], const int p[3],
+                            void* ws, size_t ws_bytes, hipStream_t stream, const char* tag, size_t* need_only) {
+    static const bool off = getenv("DCV_NO_STEM3D_WGRAD") != nullptr;
+    if (off || eff_precision() == 1) return -1;
+    const int DC = dd.c, GC = gd.c;
+    if (DC != 32 || GC < 1 || GC > 3 || dd.sw != 1 || gd.sw != 1 || dd.n != gd.n) return -1;
+    if (!(k[0] == 4 && k[1] == 4 && k[2] == 4 && s[0] == 1 && s[1] == 2 && s[2] == 2 && p[0] == 0 && p[1] == 1 && p[2] == 1)) return -1;
+    if (gd.w != 64 || dd.w != 32 || gd.h != 2 * dd.h || dd.h < 1 || gd.d != dd.d + 3 || dd.d < 1) return -1;
+    // 16-byte LDS-DMA granules: rows of both operands on 16-byte addresses
+    if (gd.sn % 4 || gd.sc % 4 || gd.sd % 4 || gd.sh % 4 || dd.sn % 4 || dd.sc % 4 || dd.sd % 4 || dd.sh % 4 ||
+        (G && (reinterpret_cast<uintptr_t>(G) & 15) != 0) || (D && (reinterpret_cast<uintptr_t>(D) & 15) != 0))
+        return -1;
+    // 32-bit byte offsets inside one sample (the kernel's buffer resources start at the sample)
+    if (gd.sc < 0 || gd.sd < 0 || gd.sh < 0 || dd.sc < 0 || dd.sd < 0 || dd.sh < 0) return -1;
+    if ((int64_t)(GC - 1) * gd.sc + (int64_t)(gd.d - 1) * gd.sd + (int64_t)(gd.h - 1) * gd.sh + 64 >= (1ll << 28) ||
+        (int64_t)31 * dd.sc + (int64_t)(dd.d - 1) * dd.sd + (int64_t)(dd.h - 1) * dd.sh + 32 >= (1ll << 28))
+        return -1;
+    const int64_t rows64 = (int64_t)dd.n * dd.d * dd.h;
+    if (rows64 < 1 || rows64 >= (1 << 30)) return -1;
+    const int rows = (int)rows64, J = 64 * GC;
+    static const int ns_env = getenv("DCV_STEM3D_STAGES") ? atoi(getenv("DCV_STEM3D_STAGES")) : 0;      // A/B only
+    const int NS = ns_env >= 2 && ns_env <= 4 ? ns_env : (GC == 3 ? 2 : 4);      // measured at B = 70: 1 channel 0.092 / 0.095 / 0.083 ms with 2 / 3 / 4 stages, 3 channels 0.144 / 0.164 / 0.226
+    const int stage_bytes = (GC * 1024 + 1024) * 4;
+    const int cap = 256 * std::max(1, std::min(8, (159 * 1024) / (NS * stage_bytes)));      // waves the chip holds at this LDS footprint
+    const int rpw = std::max(8, (rows + cap - 1) / cap);
+    const int nwg = (rows + rpw - 1) / rpw;
+    const size_t need = align_up((size_t)nwg * 32 * J * sizeof(float), 256);
+    if (need_only) {
+        *need_only = need + 256;
+        return DCV_OK;
+    }
+    if (!D || !G || !R || !ws) return fail(DCV_EINVAL, "%s: null pointer", tag);
+    if (need > ws_bytes) return fail(DCV_EWORKSPACE, "%s: workspace too small (%zu needed, %zu given)", tag, need, ws_bytes);
+    Stem3Args a;
+    memset(&a, 0, sizeof(a));
+    a.d = D; a.g = G; a.slab = static_cast<float*>(ws);
+    a.d_sn = dd.sn; a.g_sn = gd.sn;
+    a.d_sc = (int32_t)dd.sc; a.d_sd = (int32_t)dd.sd; a.d_sh = (int32_t)dd.sh;
+    a.g_sc = (int32_t)gd.sc; a.g_sd = (int32_t)gd.sd; a.g_sh = (int32_t)gd.sh;
+    a.OD = dd.d; a.OH = dd.h; a.H = gd.h; a.rows = rows; a.rpw = rpw; a.J = J;
+#define DCV_STEM3(C_, N_) hipLaunchKernelGGL((stem3d_wgrad_kernel<C_, N_>), dim3((unsigned)nwg), dim3(64), 0, stream, a)
+    if (GC == 1) { if (NS == 2) DCV_STEM3(1, 2); else if (NS == 3) DCV_STEM3(1, 3); else DCV_STEM3(1, 4); }
+    else if (GC == 2) { if (NS == 2) DCV_STEM3(2, 2); else if (NS == 3) DCV_STEM3(2, 3); else DCV_STEM3(2, 4); }
+    else { if (NS == 2) DCV_STEM3(3, 2); else if (NS == 3) DCV_STEM3(3, 3); else DCV_STEM3(3, 4); }
+#undef DCV_STEM3
+    DCV_NOTE_KERNEL("stem3d_wgrad_kernel<%d, %d stages> (%d waves x %d output rows)", GC, NS, nwg, rpw);
+    DCV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((32 * J / 4 + 63) / 64)), dim3(256), 0, stream, a.slab, R, nwg, 32, J, 32, J, t_wgrad_acc);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R,
                      const int k[3], const int s[3], const int p[3], void* ws, size_t ws_bytes, hipStream_t stream, const char* tag,
                      size_t* need_only) {
@@ -3883,6 +4065,12 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
         const int rc_ = try_thinj_wgrad(D, dd, G, gd, R, k, s, p, ws, ws_bytes, stream, tag, need_only ? &tj_need : nullptr);
         if (rc_ != -1 && !need_only) return rc_;
         thin_need = std::max(thin_need, tj_need);
+    }
+    {   // the 3-D discriminators' stems: one wave per run of output rows, everything staged once
+        size_t st_need = 0;
+        const int rc_ = try_stem3d_wgrad(D, dd, G, gd, R, k, s, p, ws, ws_bytes, stream, tag, need_only ? &st_need : nullptr);
+        if (rc_ != -1 && !need_only) return rc_;
+        thin_need = std::max(thin_need, st_need);
     }
     const int J = (int)J64;
     const WgradTile tc = pick_wgrad_tile(DC, J);
