@@ -2975,6 +2975,201 @@ __global__ __launch_bounds__(64) void stem3d_wgrad_kernel(const Stem3Args a) {
 }
 
 // --------------------------------------------------------------------------- //
+// The discriminators' heads: Conv2d / Conv3d(C -> 1, 4x4(x4), stride (1,)2,2, padding (0,)1,1) on 8 x 8 planes -> 4 x 4 (discriminator.py: the last layer of the
+// image / video / gradient discriminators; C = 256 / 256 / 128).  0.01-0.15 GFLOP on 8-32 MB of input: the tile kernels run them at 20-90 us per launch, latency
+// bound (split-K gathers of single dwords, 128 x 128 tiles with one live column), and the iteration pays those launches one for one (profiles/r06_ab_heads.txt).
+// All three passes share one lane map, chosen so that the weights are WAVE-UNIFORM: a workgroup takes four input planes (n, d); its wave q = (ph, pw) owns the
+// pixels of one row / column PARITY of those planes (lane = plane, row pair, column pair).  A pixel (h, w) meets only the taps kh = 1 - ph + 2 a, kw = 1 - pw + 2 b
+// (a, b in {0, 1}), i.e. 4 ND taps per channel, the same for every lane of the wave: scalar loads, 4 ND FMAs per loaded pixel, no LDS in the channel loop.
+//   head_fwd_kernel   x * w into 4 ND per-lane sums over a channel range; the 16 pixels x taps that make an output position meet in LDS and are added in tap order;
+//                     one partial [4 x 4] per (channel split, input plane, depth tap) -> head_fwd_combine_kernel adds splits and depth taps in order, applies act;
+//   head_dgrad_kernel dx = sum over the 4 ND (depth tap, a, b) of dy[.] * w: a pure stream of the 8-32 MB gradient;
+//   head_wgrad_kernel one workgroup per channel walks every plane: x * dy into 4 ND sums per lane, one wave reduction at the end, each wave stores its parity's
+//                     4 ND weights (dw += for the second use of a weight in one backward).
+// Every order is fixed: bitwise reproducible.  Roofline: HBM (the input read once: 4-6 us at B = 70).
+// --------------------------------------------------------------------------- //
+struct HeadArgs {
+    const float* x; const float* w; const float* dy; float* out; float* part;
+    int64_t x_sn, y_sn;
+    int32_t x_sc, x_sd, y_sd;
+    int32_t N, C, D, OD;           // samples, channels, input planes per sample, output planes per sample (D = OD + ND - 1)
+    int32_t CS, cper;              // forward: channel splits, channels per split
+    int32_t act, accumulate;
+    float slope; int32_t pad;
+};
+
+// lane map shared by the three kernels: plane pj of the group, pixel (h, w) of parity (ph, pw)
+#define DCV_HEAD_LANES()                                                                  \
+    const int tid = threadIdx.x, lane = tid & 63;                                         \
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6), ph = q >> 1, pw = q & 1;      \
+    const int pj = lane >> 4, i_ = (lane >> 2) & 3, j_ = lane & 3;                        \
+    const int h = 2 * i_ + ph, w_ = 2 * j_ + pw;
+
+template <int ND>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
+    __shared__ float S[4][64][ND * 4];
+    DCV_HEAD_LANES()
+    const int NP = a.N * a.D;
+    const int pidx = (int)blockIdx.x * 4 + pj;
+    const bool valid = pidx < NP;
+    const int n = valid ? pidx / a.D : 0, d = valid ? pidx - n * a.D : 0;
+    const float* __restrict__ xp = a.x + (int64_t)n * a.x_sn + (int64_t)d * a.x_sd + h * 8 + w_;
+    const int c0 = (int)blockIdx.y * a.cper, c1 = min(a.C, c0 + a.cper);
+    float acc[ND][2][2];
+#pragma unroll
+    for (int kd = 0; kd < ND; ++kd) { acc[kd][0][0] = acc[kd][0][1] = acc[kd][1][0] = acc[kd][1][1] = 0.f; }
+    const float* __restrict__ wq = a.w + (1 - ph) * 4 + (1 - pw);      // wave-uniform: this parity's taps are wq[kd * 16 + a * 8 + b * 2]
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+        const float xv = valid ? xp[(int64_t)c * a.x_sc] : 0.f;
+        const float* __restrict__ wc = wq + (int64_t)c * (ND * 16);
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd)
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) acc[kd][aa][bb] += xv * wc[kd * 16 + aa * 8 + bb * 2];
+    }
+#pragma unroll
+    for (int kd = 0; kd < ND; ++kd)
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) S[q][lane][kd * 4 + aa * 2 + bb] = acc[kd][aa][bb];
+    __syncthreads();
+    // thread -> (plane of the group, depth tap, output position): the 16 (kh, kw) contributions in tap order
+    const int t_pj = tid >> 6, t_kd = (tid >> 4) & 3, oh = (tid >> 2) & 3, ow = tid & 3;
+    const int t_pidx = (int)blockIdx.x * 4 + t_pj;
+    if (t_kd >= ND || t_pidx >= NP) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh) {
+        const int hh = 2 * oh - 1 + kh;
+        if (hh < 0 || hh > 7) continue;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int ww = 2 * ow - 1 + kw;
+            if (ww < 0 || ww > 7) continue;
+            sum += S[(hh & 1) * 2 + (ww & 1)][t_pj * 16 + (hh >> 1) * 4 + (ww >> 1)][t_kd * 4 + (kh >> 1) * 2 + (kw >> 1)];
+        }
+    }
+    a.part[(((int64_t)blockIdx.y * NP + t_pidx) * ND + t_kd) * 16 + oh * 4 + ow] = sum;
+}
+
+// y[n][od][oh][ow] = act(sum over channel splits, then depth taps, of part[split][n D + od + kd][kd][oh][ow])
+template <int ND>
+__global__ __launch_bounds__(256) void head_fwd_combine_kernel(const HeadArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t tot = (int64_t)a.N * a.OD * 16;
+    if (i >= tot) return;
+    const int pos = (int)(i & 15);
+    const int64_t r = i >> 4;
+    const int n = (int)(r / a.OD), od = (int)(r - (int64_t)n * a.OD);
+    const int NP = a.N * a.D;
+    float sum = 0.f;
+    for (int cs = 0; cs < a.CS; ++cs)
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd) sum += a.part[(((int64_t)cs * NP + (int64_t)n * a.D + od + kd) * ND + kd) * 16 + pos];
+    a.out[(int64_t)n * a.y_sn + (int64_t)od * a.y_sd + pos] = apply_act(sum, a.act, a.slope);
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const HeadArgs a) {
+    DCV_HEAD_LANES()
+    const int NP = a.N * a.D;
+    const int pidx = (int)blockIdx.x * 4 + pj;
+    if (pidx >= NP) return;
+    const int n = pidx / a.D, d = pidx - n * a.D;
+    // the 4 ND cotangent values this pixel meets: output plane d - kd, position (i + ph - a, j + pw - b)
+    float g[ND][2][2];
+#pragma unroll
+    for (int kd = 0; kd < ND; ++kd)
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int od = d - kd, oh = i_ + ph - aa, ow = j_ + pw - bb;
+                const bool ok = od >= 0 && od < a.OD && (unsigned)oh < 4u && (unsigned)ow < 4u;
+                g[kd][aa][bb] = ok ? a.dy[(int64_t)n * a.y_sn + (int64_t)od * a.y_sd + oh * 4 + ow] : 0.f;
+            }
+    float* __restrict__ op = a.out + (int64_t)n * a.x_sn + (int64_t)d * a.x_sd + h * 8 + w_;
+    const float* __restrict__ wq = a.w + (1 - ph) * 4 + (1 - pw);
+    const int c0 = (int)blockIdx.y * a.cper, c1 = min(a.C, c0 + a.cper);
+#pragma unroll 4
+    for (int c = c0; c < c1; ++c) {
+        const float* __restrict__ wc = wq + (int64_t)c * (ND * 16);
+        float v = 0.f;
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd)
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) v += g[kd][aa][bb] * wc[kd * 16 + aa * 8 + bb * 2];
+        float* o = op + (int64_t)c * a.x_sc;
+        *o = a.accumulate ? *o + v : v;
+    }
+}
+
+// blockIdx.x = group of CG channels, blockIdx.y = share of the plane groups; the cotangent values a pixel meets are formed once per plane and used for all CG channels.
+// part[share][channel][ND * 16]: the shares are added (also into an existing gradient) by wgrad_reduce_kernel, in order.
+template <int ND, int CG>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const HeadArgs a) {
+    DCV_HEAD_LANES()
+    const int NP = a.N * a.D, c0 = (int)blockIdx.x * CG;
+    const int ngroups = (NP + 3) / 4, gper = (ngroups + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int g0 = (int)blockIdx.y * gper, g1 = min(ngroups, g0 + gper);
+    float acc[CG][ND * 4];
+#pragma unroll
+    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+        for (int e = 0; e < ND * 4; ++e) acc[cc][e] = 0.f;
+    // (a, b) positions of this pixel: lane constants
+    int pos[4];
+    bool pok[4];
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+        const int oh = i_ + ph - (ab >> 1), ow = j_ + pw - (ab & 1);
+        pok[ab] = (unsigned)oh < 4u && (unsigned)ow < 4u;
+        pos[ab] = pok[ab] ? oh * 4 + ow : 0;
+    }
+    const float* __restrict__ xc = a.x + (int64_t)c0 * a.x_sc + h * 8 + w_;
+    for (int gi = g0; gi < g1; ++gi) {
+        const int pidx = gi * 4 + pj;
+        const bool valid = pidx < NP;
+        const int n = valid ? pidx / a.D : 0, d = valid ? pidx - n * a.D : 0;
+        float gv[ND * 4];
+#pragma unroll
+        for (int kd = 0; kd < ND; ++kd) {
+            const int od = d - kd;
+            const bool dok = valid && od >= 0 && od < a.OD;
+            const float* __restrict__ gp = a.dy + (int64_t)n * a.y_sn + (int64_t)(dok ? od : 0) * a.y_sd;
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) gv[kd * 4 + ab] = (dok && pok[ab]) ? gp[pos[ab]] : 0.f;
+        }
+        const float* __restrict__ xp = xc + (int64_t)n * a.x_sn + (int64_t)d * a.x_sd;
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc) {
+            const float xv = (valid && c0 + cc < a.C) ? xp[(int64_t)cc * a.x_sc] : 0.f;
+#pragma unroll
+            for (int e = 0; e < ND * 4; ++e) acc[cc][e] += xv * gv[e];
+        }
+    }
+    // the wave's 64 lanes -> one number per (channel, kd, a, b), in a fixed butterfly order
+    float* __restrict__ out = a.part + ((int64_t)blockIdx.y * a.C) * (ND * 16);
+#pragma unroll
+    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+        for (int e = 0; e < ND * 4; ++e) {
+            float v = acc[cc][e];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0 && c0 + cc < a.C)
+                out[(int64_t)(c0 + cc) * (ND * 16) + (e >> 2) * 16 + ((1 - ph) + 2 * ((e >> 1) & 1)) * 4 + (1 - pw) + 2 * (e & 1)] = v;
+        }
+}
+#undef DCV_HEAD_LANES
+
+// --------------------------------------------------------------------------- //
 // host side: plans (index tables cached on the device per distinct geometry)
 // --------------------------------------------------------------------------- //
 struct DevTable {
@@ -3995,6 +4190,77 @@ static int try_thinj_wgrad(const float* D, const dcv_dims5& dd, const float* G, 
     return DCV_OK;
 }
 
+// the discriminators' heads (head_fwd / head_dgrad / head_wgrad kernels): x = the module's input (N, C, D, 8, 8), y = its output (N, 1, OD, 4, 4)
+static bool head_shape_ok(const int k[3], const int s[3], const int p[3], bool transposed, const dcv_dims5& x, const dcv_dims5& y) {
+    static const bool off = getenv("DCV_NO_HEAD_KERNELS") != nullptr;
+    if (off || transposed || eff_precision() == 1) return false;
+    if (!((k[0] == 1 || k[0] == 4) && k[1] == 4 && k[2] == 4 && s[0] == 1 && s[1] == 2 && s[2] == 2 && p[0] == 0 && p[1] == 1 && p[2] == 1)) return false;
+    if (y.c != 1 || x.h != 8 || x.w != 8 || x.sh != 8 || x.sw != 1 || y.h != 4 || y.w != 4 || y.sh != 4 || y.sw != 1 || x.d != y.d + k[0] - 1 || y.d < 1 || x.n != y.n) return false;
+    if (x.c < 1 || x.sc < 0 || x.sd < 0 || x.sn < 0 || y.sd < 0 || y.sn < 0 || x.sc >= (1ll << 30) || x.sd >= (1ll << 30) || y.sd >= (1ll << 30)) return false;
+    return (int64_t)x.n * x.d < (1ll << 28);
+}
+static int head_splits(const dcv_dims5& x) {      // forward: channel splits so that ~1000 workgroups exist
+    const int groups = (int)(((int64_t)x.n * x.d + 3) / 4);
+    int cs = std::max(1, std::min(x.c / 16, (1024 + groups - 1) / groups));
+    return std::min(cs, 16);
+}
+static size_t head_fwd_bytes(const dcv_dims5& x, int nd) { return align_up((size_t)head_splits(x) * x.n * x.d * nd * 16 * sizeof(float), 256) + 256; }
+static HeadArgs head_args(const dcv_dims5& x, const dcv_dims5& y, int nd) {
+    HeadArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x_sn = x.sn; a.y_sn = y.sn; a.x_sc = (int32_t)x.sc; a.x_sd = (int32_t)x.sd; a.y_sd = (int32_t)y.sd;
+    a.N = x.n; a.C = x.c; a.D = x.d; a.OD = y.d;
+    (void)nd;
+    return a;
+}
+static int run_head_fwd(const float* x, const dcv_dims5& xd, const float* w, float* y, const dcv_dims5& yd, int nd, int act, float slope, void* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = head_fwd_bytes(xd, nd);
+    if (!ws || need > ws_bytes) return fail(DCV_EWORKSPACE, "conv_fwd (head): workspace too small (%zu needed, %zu given)", need, ws_bytes);
+    HeadArgs a = head_args(xd, yd, nd);
+    a.x = x; a.w = w; a.out = y; a.part = static_cast<float*>(ws);
+    a.CS = head_splits(xd); a.cper = (xd.c + a.CS - 1) / a.CS; a.act = act; a.slope = slope;
+    const dim3 grid((unsigned)(((int64_t)xd.n * xd.d + 3) / 4), (unsigned)a.CS);
+    const unsigned cb = (unsigned)(((int64_t)yd.n * yd.d * 16 + 255) / 256);
+    if (nd == 1) { hipLaunchKernelGGL((head_fwd_kernel<1>), grid, dim3(256), 0, st, a); hipLaunchKernelGGL((head_fwd_combine_kernel<1>), dim3(cb), dim3(256), 0, st, a); }
+    else { hipLaunchKernelGGL((head_fwd_kernel<4>), grid, dim3(256), 0, st, a); hipLaunchKernelGGL((head_fwd_combine_kernel<4>), dim3(cb), dim3(256), 0, st, a); }
+    DCV_NOTE_KERNEL("head_fwd_kernel<%d> (%d plane groups x %d channel splits)", nd, (int)grid.x, a.CS);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+static int run_head_dgrad(const float* dy, const dcv_dims5& yd, const float* w, float* dx, const dcv_dims5& xd, int nd, int accumulate, hipStream_t st) {
+    HeadArgs a = head_args(xd, yd, nd);
+    a.dy = dy; a.w = w; a.out = dx; a.accumulate = accumulate;
+    a.CS = std::max(1, std::min(xd.c / 16, 8)); a.cper = (xd.c + a.CS - 1) / a.CS;
+    const dim3 grid((unsigned)(((int64_t)xd.n * xd.d + 3) / 4), (unsigned)a.CS);
+    if (nd == 1) hipLaunchKernelGGL((head_dgrad_kernel<1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((head_dgrad_kernel<4>), grid, dim3(256), 0, st, a);
+    DCV_NOTE_KERNEL("head_dgrad_kernel<%d> (%d plane groups x %d channel splits)", nd, (int)grid.x, a.CS);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+static int head_wgrad_shares(const dcv_dims5& x) {      // plane shares so that (C / 8) x shares workgroups fill the chip once
+    const int groups = (int)(((int64_t)x.n * x.d + 3) / 4), cgs = (x.c + 7) / 8;
+    return std::max(1, std::min(std::min(groups, 32), (512 + cgs - 1) / cgs));
+}
+static size_t head_wgrad_bytes(const dcv_dims5& x, int nd) { return align_up((size_t)head_wgrad_shares(x) * x.c * nd * 16 * sizeof(float), 256) + 256; }
+static int run_head_wgrad(const float* x, const dcv_dims5& xd, const float* dy, const dcv_dims5& yd, float* dw, int nd, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = head_wgrad_bytes(xd, nd);
+    if (!ws || need > ws_bytes) return fail(DCV_EWORKSPACE, "conv_bwd_weight (head): workspace too small (%zu needed, %zu given)", need, ws_bytes);
+    HeadArgs a = head_args(xd, yd, nd);
+    a.x = x; a.dy = dy; a.part = static_cast<float*>(ws);
+    const int shares = head_wgrad_shares(xd);
+    const dim3 grid((unsigned)((xd.c + 7) / 8), (unsigned)shares);
+    if (nd == 1) hipLaunchKernelGGL((head_wgrad_kernel<1, 8>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((head_wgrad_kernel<4, 8>), grid, dim3(256), 0, st, a);
+    DCV_NOTE_KERNEL("head_wgrad_kernel<%d> (%d channel groups x %d plane shares)", nd, (int)grid.x, shares);
+    DCV_LAUNCH_CHECK();
+    const int J = nd * 16;
+    const int64_t tot = (int64_t)xd.c * J;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, st, a.part, dw, shares, xd.c, J, xd.c, J, accumulate);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 // the 3-D discriminators' stems (stem3d_wgrad_kernel): -1 = not this shape
 static int try_stem3d_wgrad(const float* D, const dcv_dims5& dd, const float* G, const dcv_dims5& gd, float* R, const int k[3], const int s[3], const int p[3],
                             void* ws, size_t ws_bytes, hipStream_t stream, const char* tag, size_t* need_only) {
@@ -4056,6 +4322,11 @@ static int run_wgrad(const float* D, const dcv_dims5& dd, const float* G, const 
     const int64_t J64 = (int64_t)GC * T;
     if (J64 >= (1 << 30)) return fail(DCV_EUNSUPPORTED, "%s: J too large", tag);
     size_t thin_need = 0;
+    if (head_shape_ok(k, s, p, false, gd, dd) && dd.c == 1) {      // a discriminator's head (conv: dense = dy with one channel, gathered = x)
+        if (need_only) { *need_only = head_wgrad_bytes(gd, k[0]); return DCV_OK; }
+        if (!D || !G || !R) return fail(DCV_EINVAL, "%s: null pointer", tag);
+        return run_head_wgrad(G, gd, D, dd, R, k[0], t_wgrad_acc, ws, ws_bytes, stream);
+    }
     {   // the colour generator's stem: VALU kernel
         const int rc_ = try_thin_wgrad(D, dd, G, gd, R, k, s, p, ws, ws_bytes, stream, tag, need_only ? &thin_need : nullptr);
         if (rc_ != -1 && !need_only) return rc_;
@@ -4426,11 +4697,23 @@ static int conv_dispatch(int which, const dcv_conv_geom* g, const float* a_, con
             *pack_need = gather_pack_bytes(RC, OC, cls);
             return DCV_OK;
         }
+        const bool head = !stat && !gate && head_shape_ok(k, s, p, g->transposed != 0, *xd, *yd);
         if (need_only) {
             *need_only = gather_ws_bytes(RC, OC, dst.n, cls);
+            if (head && which == 0) *need_only = std::max(*need_only, head_fwd_bytes(*xd, k[0]));
             return DCV_OK;
         }
         if (!a_ || !w || !out) return fail(DCV_EINVAL, "conv: null pointer");
+        // a discriminator's head, C -> 1 on 8 x 8 planes.  Measured at B = 70 (profiles/r06_ab_heads.txt): the forward kernel wins for the 3-D heads (0.081 -> 0.028 ms,
+        // 0.035 -> 0.019) and ties for the 2-D one; the data-gradient kernel wins for the 2-D head (0.046 -> 0.014) and loses to the tile kernel for the 3-D ones
+        if (head && which == 0 && k[0] == 4) {
+            if (stat_parts) *stat_parts = 0;
+            return run_head_fwd(a_, *xd, w, out, *yd, k[0], act, slope, ws, ws_bytes, st);
+        }
+        if (head && which == 1 && k[0] == 1) {
+            if (stat_parts) *stat_parts = 0;
+            return run_head_dgrad(a_, *yd, w, out, *xd, k[0], accumulate, st);
+        }
         if (!direct && !stat && !gate && try_thin_quad(a_, src, out, dst, w, k, s, p, act, slope, accumulate, st)) {
             if (stat_parts) *stat_parts = 0;
             DCV_LAUNCH_CHECK();
