@@ -2845,6 +2845,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// Many slabs, few elements (stem3d_wgrad_kernel: ~1000-2000 slabs of 2-6 k elements): wgrad_reduce4_kernel gives an element one column of FOUR threads, i.e. S / 4
+// dependent-latency loads per thread on 8-24 workgroups — 20-25 us, a third of the stem kernel's own time.  Here a float4 of elements gets 64 threads, each with four
+// independent partial sums over the slabs g, g + 64, ...; the 64 partials meet in LDS and are added in group order by one thread.  Fixed order: bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S, int E4, int acc) {      // E4 float4 elements per slab, dw [4 E4]
+    constexpr int EPB = 4, G = 64;
+    __shared__ float4 part[G][EPB];
+    const int e = threadIdx.x & (EPB - 1), grp = threadIdx.x >> 2;
+    const int64_t i = (int64_t)blockIdx.x * EPB + e;
+    const bool ok = i < E4;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(slab) + (ok ? i : 0);
+    float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    if (ok) {
+        int k = grp;
+        for (; k + 3 * G < S; k += 4 * G) {
+            const float4 t0 = p[(int64_t)k * E4], t1 = p[(int64_t)(k + G) * E4], t2 = p[(int64_t)(k + 2 * G) * E4], t3 = p[(int64_t)(k + 3 * G) * E4];
+            add(s0, t0); add(s1, t1); add(s2, t2); add(s3, t3);
+        }
+        for (; k < S; k += G) add(s0, p[(int64_t)k * E4]);
+    }
+    part[grp][e] = float4{(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+    __syncthreads();
+    if (grp == 0 && ok) {
+        float4 r = part[0][e];
+        for (int g = 1; g < G; ++g) add(r, part[g][e]);
+        float4* o = reinterpret_cast<float4*>(dw) + i;
+        if (acc) { const float4 old = *o; r = float4{old.x + r.x, old.y + r.y, old.z + r.z, old.w + r.w}; }      // = the sum autograd would form of the two gradients (one rounding)
+        *o = r;
+    }
+}
+
 // --------------------------------------------------------------------------- //
 // stem3d_wgrad_kernel<CIN>: weight gradient of the 3-D discriminators' stems — Conv3d(CIN -> 32, 4x4x4, stride (1,2,2), padding (0,1,1)) on 64-wide frames
 // (discriminator.py: the depth / flow and colour branches of VideoDiscriminator, GradientDiscriminator's first layer; CIN = 1, 2, 3), R[oc][j] = sum_m dy[oc][m]
@@ -4283,7 +4314,7 @@ static int try_stem3d_wgrad(const float* D, const dcv_dims5& dd, const float* G,
     if (rows64 < 1 || rows64 >= (1 << 30)) return -1;
     const int rows = (int)rows64, J = 64 * GC;
     static const int ns_env = getenv("DCV_STEM3D_STAGES") ? atoi(getenv("DCV_STEM3D_STAGES")) : 0;      // A/B only
-    const int NS = ns_env >= 2 && ns_env <= 4 ? ns_env : (GC == 3 ? 2 : 4);      // measured at B = 70: 1 channel 0.092 / 0.095 / 0.083 ms with 2 / 3 / 4 stages, 3 channels 0.144 / 0.164 / 0.226
+    const int NS = ns_env >= 2 && ns_env <= 4 ? ns_env : 2;      // measured at B = 70 with the wide slab reduce: 1 channel 0.059 / 0.069 / 0.067 ms with 2 / 3 / 4 stages, 3 channels 0.130 / 0.156 / 0.221
     const int stage_bytes = (GC * 1024 + 1024) * 4;
     const int cap = 256 * std::max(1, std::min(8, (159 * 1024) / (NS * stage_bytes)));      // waves the chip holds at this LDS footprint
     const int rpw = std::max(8, (rows + cap - 1) / cap);
@@ -4309,7 +4340,10 @@ static int try_stem3d_wgrad(const float* D, const dcv_dims5& dd, const float* G,
 #undef DCV_STEM3
     DCV_NOTE_KERNEL("stem3d_wgrad_kernel<%d, %d stages> (%d waves x %d output rows)", GC, NS, nwg, rpw);
     DCV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((32 * J / 4 + 63) / 64)), dim3(256), 0, stream, a.slab, R, nwg, 32, J, 32, J, t_wgrad_acc);
+    if ((reinterpret_cast<uintptr_t>(R) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((8 * J + 3) / 4)), dim3(256), 0, stream, a.slab, R, nwg, 8 * J, t_wgrad_acc);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((32 * J + 63) / 64)), dim3(256), 0, stream, a.slab, R, nwg, 32, J, 32, J, t_wgrad_acc);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
