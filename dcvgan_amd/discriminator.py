@@ -9,6 +9,7 @@ B == 1 loses its batch dim as in the reference), state_dict keys
 from __future__ import annotations
 
 import json
+import os
 
 import torch
 import torch.nn as nn
@@ -18,6 +19,8 @@ from .rng import default_rng
 
 _S3, _P3 = (1, 2, 2), (0, 1, 1)
 
+
+_NO_STEM_GATE = os.environ.get("DCV_NO_STEM_GATE") is not None      # A/B: the stems run their own activation-derivative passes
 
 class Noise(nn.Module):
     """x + sigma * N(0,1) when enabled — in train AND eval mode (discriminator.py:30-39)."""
@@ -69,9 +72,10 @@ class _PairDiscriminator(nn.Module):
             hc = layers.run(self.conv_c, ops_cl.from_f32(xc), rng, out=cat.first)
             return ops_cl.to_f32(layers.run(self.main, cat.join(hc, hg), rng)).squeeze()
         cat = ops.ConcatBuffer(xg.shape[0], half, half, sp, xg.device)
-        hg = layers.run(self.conv_g, xg, rng, out=cat.second)   # draw order: geometry stem first (discriminator.py:122-123)
-        hc = layers.run(self.conv_c, xc, rng, out=cat.first)
-        return layers.run(self.main, cat.join(hc, hg), rng).squeeze()
+        hg = layers.run(self.conv_g, xg, rng, out=cat.second, act_slot=cat.slot)   # draw order: geometry stem first (discriminator.py:122-123)
+        hc = layers.run(self.conv_c, xc, rng, out=cat.first, act_slot=cat.slot)
+        # the trunk's first convolution applies the stems' LeakyReLU derivative in its data gradient's epilogue (read off the buffer; a Noise layer in between only adds)
+        return layers.run(self.main, cat.join(hc, hg), rng, gate=None if _NO_STEM_GATE else (cat.buf, cat.slot)).squeeze()
 
 
 class ImageDiscriminator(_PairDiscriminator):

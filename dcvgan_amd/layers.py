@@ -73,14 +73,17 @@ def batch_norm(bn, x, rng, act=(ops.ACT_NONE, 0.0), dropout=None, out=None, part
                       num_batches_tracked=bn.num_batches_tracked if training else None, link=link)
 
 
-def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_slot=None, bn_link=None) -> torch.Tensor:
+def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_slot=None, bn_link=None, gate=None) -> torch.Tensor:
     """`out`: destination view for the sequence's LAST fused op (a concat-buffer slice), when that
     op is a conv(+act) or a BatchNorm group.  `grad_slot`: ops.GradSlot of the concat buffer that holds x
     (x is a skip tensor): passed to the FIRST convolution, whose data gradient then accumulates into it.
     `act_slot`: ops.GradSlot of the concat buffer `out` belongs to, for a conv + (Leaky)ReLU that ends the sequence.
     `bn_link`: ops.BnLink — given to the sequence's LAST BatchNorm group when it ends the sequence (the producer side), and to its FIRST convolution
-    (the consumer side); fp32 path only."""
+    (the consumer side); fp32 path only.
+    `gate`: (concat buffer, its ops.GradSlot) — given to the sequence's FIRST convolution when x is that buffer or a Noise layer's copy of it and the buffer's halves were
+    written by conv + LeakyReLU stems with `act_slot=` that slot: the convolution's data gradient applies the stems' activation derivative (fp32 path only)."""
     layers = list(seq)
+    first_conv = True
     i, n = 0, len(layers)
     pending = None   # BatchNorm partial sums left by the conv that produced x (conv -> BN pairs in training mode)
     while i < n:
@@ -101,12 +104,15 @@ def run(seq: nn.Sequential, x: torch.Tensor, rng, out=None, grad_slot=None, act_
             fused = _act_of(nxt) if nxt is not None else None
             if fused is not None:
                 x = ops.conv(x, layer.weight, geom_of(layer), fused[0], fused[1], out=out if i + 2 >= n else None, grad_slot=grad_slot if i == 0 else None,
-                             act_slot=act_slot if i + 2 >= n else None, bn_link=bn_link if i == 0 else None)
+                             act_slot=act_slot if i + 2 >= n else None, bn_link=bn_link if i == 0 else None, gate=gate if first_conv else None)
+                first_conv = False
                 _tap(x, fused)
                 i += 2
             else:
                 box = [] if (isinstance(nxt, _BNS) and nxt.training and _FUSE_BN_STATS) else None
-                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None, bn_stats=box, grad_slot=grad_slot if i == 0 else None)
+                x = ops.conv(x, layer.weight, geom_of(layer), out=out if i + 1 >= n else None, bn_stats=box, grad_slot=grad_slot if i == 0 else None,
+                             gate=gate if first_conv else None)
+                first_conv = False
                 pending = box[0] if box else None
                 i += 1
         elif isinstance(layer, _BNS):

@@ -324,9 +324,10 @@ class _Conv(Function):
     _epoch = [object()]
 
     @staticmethod
-    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None, act_slot=None, bn_link=None):
+    def forward(ctx, x, w, g: ConvGeom, act: int, slope: float, out=None, bn_stats=None, grad_slot=None, act_slot=None, bn_link=None, gate=None):
         N._require(x, "conv input"); N._require(w, "conv weight")
         ctx.grad_slot = grad_slot
+        ctx.gate = gate if (_GATED_DGRAD and gate is not None and gate[1] is not None) else None
         ctx.bn_link = bn_link if _HEAD_BN_FUSION else None
         ctx.act_slot = act_slot if (act_slot is not None and act == ACT_LEAKY) else None
         if ctx.act_slot is not None:
@@ -385,9 +386,9 @@ class _Conv(Function):
         g = ctx.g
         L = lib()
         dy = _dense(dy)
-        fused_away = ctx.act_slot is not None and ctx.act_slot.act_applied    # the consumer's data gradient already applied act'
+        fused_away = ctx.act_slot is not None and bool(ctx.act_slot.act_applied)    # the consumer's data gradient already applied act'
         if ctx.act_slot is not None:
-            ctx.act_slot.act_applied = False
+            ctx.act_slot.act_applied = max(0, int(ctx.act_slot.act_applied) - 1)      # (a count: a discriminator's two stems share one buffer and one consumer)
         if ctx.act != ACT_NONE and not fused_away:
             dz = _empty(y.shape, y.device)
             dyd, yd, dzd = dims5(dy), dims5(y), dims5(dz)   # y may be a strided concat-buffer slice; dz is dense
@@ -438,6 +439,18 @@ class _Conv(Function):
                     slot.act_applied = True
                 elif rc != N.DCV_EUNSUPPORTED:
                     check(rc, "dcv_conv_backward_data_gated")
+            if rc == N.DCV_EUNSUPPORTED and ctx.gate is not None and into is None:
+                # x is (a noisy copy of) a discriminator's concat buffer whose two halves are conv + LeakyReLU stems (discriminator.py:122-124): the stems'
+                # activation derivative, read off the buffer, in this data gradient's epilogue — the stems then skip their own derivative passes
+                gbuf, gslot = ctx.gate
+                if gslot.act is not None and tuple(gbuf.shape) == tuple(dx.shape) and tuple(gbuf.stride()) == tuple(dx.stride()):
+                    gd_ = dims5(gbuf)
+                    rc = L.dcv_conv_backward_data_gated(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), 0, ptr(gbuf), C.byref(gd_),
+                                                        gslot.act[0], gslot.act[1], pkp, wsp, wsn, stream_ptr())
+                    if rc == 0:
+                        gslot.act_applied = 2
+                    elif rc != N.DCV_EUNSUPPORTED:
+                        check(rc, "dcv_conv_backward_data_gated")
             if rc == N.DCV_EUNSUPPORTED:
                 check(L.dcv_conv_backward_data(C.byref(g), ptr(dy), C.byref(dyd), ptr(w), ptr(dx), C.byref(dxd), int(into is not None),
                                                pkp, wsp, wsn, stream_ptr()), "dcv_conv_backward_data")
@@ -500,7 +513,7 @@ class _Conv(Function):
                 check(L.dcv_conv_backward_weight(C.byref(g), ptr(x), C.byref(xd), ptr(dy), C.byref(dyd), ptr(dw), wsp, wsn, stream_ptr()), "dcv_conv_backward_weight")
                 if _OWN_ACCUMULATION:
                     note_first(w, dw)
-        return dx, dw, None, None, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None, None, None
 
 
 def new_backward_epoch():
@@ -508,13 +521,13 @@ def new_backward_epoch():
     _Conv._epoch[0] = object()
 
 
-def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None, act_slot=None, bn_link=None):
+def conv(x, w, g: ConvGeom, act: int = ACT_NONE, slope: float = 0.0, out=None, bn_stats=None, grad_slot=None, act_slot=None, bn_link=None, gate=None):
     """y = act(conv(x, w)) for nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d geometries.
     `out`: optional destination view (e.g. a channel slice of a concat buffer) to write into.
     `grad_slot`: ConcatBuffer.slot of the buffer whose second slice IS x (a skip connection), see GradSlot.
     `act_slot`: ConcatBuffer.slot of the buffer this conv + (Leaky)ReLU writes its output into (`out` is its second slice).
     `bn_link`: the BnLink of the BatchNorm group that produced x's first channels (see BnLink)."""
-    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot, act_slot, bn_link)
+    return _Conv.apply(x, w, g, act, float(slope), None if out is None else _Out(out), bn_stats, grad_slot, act_slot, bn_link, gate)
 
 
 # --------------------------------------------------------------------------- #
